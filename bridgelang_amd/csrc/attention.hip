@@ -1,0 +1,306 @@
+// attention.hip — flash-style attention for the three head sizes on the OpenVLA path (64 DINOv2, 72 SigLIP,
+// 128 Llama-2) plus the single-query decode kernel.
+//
+// Prefill / ViT kernel (attn_fwd_kernel):
+//   * one workgroup = 4 waves = 64 query rows of one (batch, head); key/value chunks of 64 keys stream through LDS;
+//     online softmax (running max / sum) so the sequence length is unbounded.
+//   * QK^T is computed SWAPPED (S^T = K·Q^T: K rows are the MFMA "A" operand, Q the "B" operand), so a lane owns one
+//     query column and 4 keys per 16-key tile: the softmax row reductions are 15 in-lane ops + two cross-lane
+//     shuffles (xor 16, 32), and the fp32 scores are already laid out as the "B" operand of the PV product
+//     O^T = V^T·P^T — no LDS round trip for P (guide §3, "accumulator tile as the next MFMA's operand").
+//   * V is transposed while staging (V^T[d][key] in LDS) so the PV "A" operand is two 8-byte LDS reads per MFMA.
+//   * head_dim 72 is zero-padded in LDS to K=96 for QK^T and to 80 output rows for PV; no padded bytes touch HBM.
+//   * numerics: fp32 scores, fp32 exp/sum, P rounded to bf16 for the PV MFMA, O = bf16(acc / sum) — restated op for
+//     op by oracle/restate.py::attention.
+#include "bl_common.h"
+#include <math.h>
+
+namespace bl_attention_impl {
+
+struct AttnArgs {
+  const uint16_t* q; const uint16_t* k; const uint16_t* v; uint16_t* o; const uint8_t* mask;
+  long q_bs, q_hs, q_rs, k_bs, k_hs, k_rs, v_bs, v_hs, v_rs, o_bs, o_hs, o_rs, mask_bs;
+  int B, H, Sq, Skv;
+  float scale_log2e;
+};
+
+constexpr int KV_CHUNK = 64;
+constexpr int VROW = KV_CHUNK * 2 + 16;   // bytes per V^T row (64 keys + 16 B pad → conflict-free ds_read_b64)
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+  constexpr int HDP = (HD + 31) / 32 * 32;     // QK^T reduction length (zero padded)
+  constexpr int KS = HDP / 32;                 // MFMA k-steps for QK^T
+  constexpr int KCH = HD / 8;                  // 16-byte chunks per K/V row in HBM
+  constexpr int KROW = HDP * 2 + 16;           // LDS bytes per K row (padded against bank conflicts)
+  constexpr int DT = (HD + 15) / 16;           // 16-row output tiles of O^T
+  static_assert(HD % 8 == 0, "head_dim must be a multiple of 8");
+
+  __shared__ __attribute__((aligned(16))) char k_lds[KV_CHUNK * KROW];
+  __shared__ __attribute__((aligned(16))) char vt_lds[DT * 16 * VROW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int qrow = q0 + wave * 16 + l15;
+  const int off = p.Skv - p.Sq;                // causal: key j visible to query i iff j <= i + off
+
+  // zero the LDS padding once (never overwritten by the staging loops)
+  for (int i = tid; i < (int)sizeof(k_lds) / 16; i += 256) ((u32x4_t*)k_lds)[i] = (u32x4_t){0u, 0u, 0u, 0u};
+  for (int i = tid; i < (int)sizeof(vt_lds) / 16; i += 256) ((u32x4_t*)vt_lds)[i] = (u32x4_t){0u, 0u, 0u, 0u};
+
+  // Q fragments ("B" operand): lane holds Q[qrow][8*(lg+4ks) .. +7]
+  bf16x8_t qf[KS];
+  {
+    const uint16_t* qp = p.q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qrow * p.q_rs;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int ch = lg + 4 * ks;
+      u32x4_t t = {0u, 0u, 0u, 0u};
+      if (qrow < p.Sq && ch < KCH) t = *(const u32x4_t*)(qp + ch * 8);
+      qf[ks] = __builtin_bit_cast(bf16x8_t, t);
+    }
+  }
+
+  f32x4_t o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) o[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_part = 0.f;
+
+  int kv_end = p.Skv;
+  if (CAUSAL) kv_end = min(p.Skv, q0 + 64 + off);
+  const int nchunk = (kv_end + KV_CHUNK - 1) / KV_CHUNK;
+  const uint16_t* kbase = p.k + (long)b * p.k_bs + (long)h * p.k_hs;
+  const uint16_t* vbase = p.v + (long)b * p.v_bs + (long)h * p.v_hs;
+  const uint8_t* mrow = p.mask ? p.mask + (long)b * p.mask_bs : nullptr;
+
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int key0 = c * KV_CHUNK;
+    // ---- stage K chunk (row-major) and V chunk (transposed) ----
+    for (int piece = tid; piece < KV_CHUNK * KCH; piece += 256) {
+      const int key = piece / KCH, ch = piece - key * KCH;
+      u32x4_t t = {0u, 0u, 0u, 0u};
+      if (key0 + key < p.Skv) t = *(const u32x4_t*)(kbase + (long)(key0 + key) * p.k_rs + ch * 8);
+      *(u32x4_t*)(k_lds + key * KROW + ch * 16) = t;
+    }
+    for (int piece = tid; piece < KV_CHUNK * KCH; piece += 256) {
+      const int key = piece & 63, ch = piece >> 6;   // a wave shares ch → its 64 b16 writes are contiguous
+      u32x4_t t = {0u, 0u, 0u, 0u};
+      if (key0 + key < p.Skv) t = *(const u32x4_t*)(vbase + (long)(key0 + key) * p.v_rs + ch * 8);
+      uint16_t* dst = (uint16_t*)(vt_lds + (ch * 8) * VROW) + key;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dst[(2 * i) * (VROW / 2)] = (uint16_t)(t[i] & 0xffffu);
+        dst[(2 * i + 1) * (VROW / 2)] = (uint16_t)(t[i] >> 16);
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T = K · Q^T : lane owns query column l15 and keys 16*kt + 4*lg + r ----
+    float s[4][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t kf = *(const bf16x8_t*)(k_lds + (kt * 16 + l15) * KROW + (lg + 4 * ks) * 16);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + kt * 16 + lg * 4 + r;
+        bool vis = key < p.Skv;
+        if (CAUSAL) vis = vis && (key <= qrow + off);
+        if (mrow) vis = vis && (key < p.Skv ? mrow[key] != 0 : false);
+        s[kt][r] = vis ? acc[r] * p.scale_log2e : -INFINITY;
+      }
+    }
+    // ---- online softmax (base-2 domain) ----
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);   // m_run = -inf → 0
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8_t pf[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      float e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        e[j] = __builtin_amdgcn_exp2f(s[2 * s2 + (j >> 2)][j & 3] - m_use);
+        psum += e[j];
+      }
+      u32x4_t t;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = pack2bf(e[2 * j], e[2 * j + 1]);
+      pf[s2] = __builtin_bit_cast(bf16x8_t, t);
+    }
+    l_part = l_part * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i] *= alpha;
+
+    // ---- O^T += V^T · P^T : element j of lane group lg ↔ key 32*s2 + 16*(j>>2) + 4*lg + (j&3) on both operands ----
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const char* vp = vt_lds + (dt * 16 + l15) * VROW + (32 * s2 + 4 * lg) * 2;
+        const u32x2_t v0 = *(const u32x2_t*)vp;
+        const u32x2_t v1 = *(const u32x2_t*)(vp + 32);
+        const u32x4_t vv = {v0[0], v0[1], v1[0], v1[1]};
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pf[s2], o[dt], 0, 0, 0);
+      }
+    }
+    __syncthreads();   // everyone done with this chunk before it is overwritten
+  }
+
+  // ---- finalize: lane holds O^T[d = 16*dt + 4*lg + r][q = l15] ----
+  float l = l_part;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  if (qrow < p.Sq) {
+    uint16_t* op = p.o + (long)b * p.o_bs + (long)h * p.o_hs + (long)qrow * p.o_rs;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + lg * 4;
+      if (d < HD) {
+        u32x2_t w;
+        w[0] = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
+        w[1] = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
+        *(u32x2_t*)(op + d) = w;
+      }
+    }
+  }
+}
+
+// ---- decode: one wave per (batch, head), single query row, head_dim 128. Lane = (key group kg = lane>>4, 16-byte
+// chunk dc = lane&15): every wave-instruction reads 4 whole 256-byte K (or V) rows. ----
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
+  constexpr int MAXKV = 2048;   // head_dim is fixed at 128 (16 lanes × 16 B per row)
+  __shared__ float sc[4][MAXKV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh = blockIdx.x * 4 + wave;
+  if (bh >= p.B * p.H) return;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int kg = lane >> 4, dc = lane & 15;
+  float* s = sc[wave];
+
+  float qv[8];
+  {
+    const u32x4_t t = *(const u32x4_t*)(p.q + (long)b * p.q_bs + (long)h * p.q_hs + dc * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { qv[2 * i] = bflo(t[i]); qv[2 * i + 1] = bfhi(t[i]); }
+  }
+  const uint16_t* kbase = p.k + (long)b * p.k_bs + (long)h * p.k_hs;
+  const uint16_t* vbase = p.v + (long)b * p.v_bs + (long)h * p.v_hs;
+  const uint8_t* mrow = p.mask ? p.mask + (long)b * p.mask_bs : nullptr;
+  const int n = p.Skv;
+
+  // scores
+  for (int k0 = 0; k0 < n; k0 += 4) {
+    const int key = k0 + kg;
+    float d = 0.f;
+    if (key < n) {
+      const u32x4_t t = *(const u32x4_t*)(kbase + (long)key * p.k_rs + dc * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d += qv[2 * i] * bflo(t[i]) + qv[2 * i + 1] * bfhi(t[i]);
+    }
+    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+    if (dc == 0 && key < n) s[key] = (mrow && mrow[key] == 0) ? -INFINITY : d * p.scale_log2e;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible to its own reads
+  __builtin_amdgcn_wave_barrier();
+  float mx = -INFINITY;
+  for (int i = lane; i < n; i += 64) mx = fmaxf(mx, s[i]);
+  mx = wave_max(mx);
+  const float m_use = (mx == -INFINITY) ? 0.f : mx;
+  float l = 0.f;
+  for (int i = lane; i < n; i += 64) {
+    const float e = __builtin_amdgcn_exp2f(s[i] - m_use);
+    l += e;
+    s[i] = rbf(e);
+  }
+  l = wave_sum(l);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < n; k0 += 4) {
+    const int key = k0 + kg;
+    if (key < n) {
+      const float pk = s[key];
+      const u32x4_t t = *(const u32x4_t*)(vbase + (long)key * p.v_rs + dc * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc[2 * i] += pk * bflo(t[i]); acc[2 * i + 1] += pk * bfhi(t[i]); }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { acc[i] += __shfl_xor(acc[i], 16, 64); acc[i] += __shfl_xor(acc[i], 32, 64); }
+  if (kg == 0) {
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    u32x4_t w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = pack2bf(acc[2 * i] * inv, acc[2 * i + 1] * inv);
+    *(u32x4_t*)(p.o + (long)b * p.o_bs + (long)h * p.o_hs + dc * 8) = w;
+  }
+}
+
+int fill_args(const bl_attn_desc* d, AttnArgs& a) {
+  if (!d || !d->q || !d->k || !d->v || !d->o) return BL_E_ARG;
+  if (d->B <= 0 || d->H <= 0 || d->Sq <= 0 || d->Skv <= 0) return BL_E_SHAPE;
+  const int64_t st[] = {d->q_bs, d->q_hs, d->q_rs, d->k_bs, d->k_hs, d->k_rs, d->v_bs, d->v_hs, d->v_rs};
+  for (int64_t s : st) if (s % 8) return BL_E_ALIGN;
+  if ((d->o_bs % 4) || (d->o_hs % 4) || (d->o_rs % 4)) return BL_E_ALIGN;
+  if (!bl_aligned16(d->q) || !bl_aligned16(d->k) || !bl_aligned16(d->v) || (((uintptr_t)d->o) & 7)) return BL_E_ALIGN;
+  a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->o; a.mask = d->key_mask;
+  a.q_bs = d->q_bs; a.q_hs = d->q_hs; a.q_rs = d->q_rs; a.k_bs = d->k_bs; a.k_hs = d->k_hs; a.k_rs = d->k_rs;
+  a.v_bs = d->v_bs; a.v_hs = d->v_hs; a.v_rs = d->v_rs; a.o_bs = d->o_bs; a.o_hs = d->o_hs; a.o_rs = d->o_rs;
+  a.mask_bs = d->mask_bs;
+  a.B = d->B; a.H = d->H; a.Sq = d->Sq; a.Skv = d->Skv;
+  a.scale_log2e = d->scale * 1.44269504088896340736f;
+  return BL_OK;
+}
+
+}  // namespace bl_attention_impl
+using namespace bl_attention_impl;
+
+extern "C" int bl_attention_bf16(const bl_attn_desc* d, void* stream) {
+  AttnArgs a;
+  const int rc = fill_args(d, a);
+  if (rc != BL_OK) return rc;
+  if (d->causal && d->Skv < d->Sq) return BL_E_SHAPE;
+  const dim3 grid((d->Sq + 63) / 64, d->H, d->B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define BL_ATTN_CASE(HD)                                                                       \
+  case HD:                                                                                     \
+    if (d->causal) hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, block, 0, s, a);      \
+    else hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, block, 0, s, a);               \
+    break;
+  switch (d->head_dim) {
+    BL_ATTN_CASE(64) BL_ATTN_CASE(72) BL_ATTN_CASE(128)
+    default: return BL_E_SHAPE;
+  }
+#undef BL_ATTN_CASE
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_attention_decode_bf16(const bl_attn_desc* d, void* stream) {
+  AttnArgs a;
+  const int rc = fill_args(d, a);
+  if (rc != BL_OK) return rc;
+  if (d->head_dim != 128 || d->Sq != 1 || d->Skv > 2048) return BL_E_SHAPE;
+  if (((uintptr_t)d->o) & 15) return BL_E_ALIGN;
+  hipLaunchKernelGGL(attn_decode_kernel, dim3((d->B * d->H + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}

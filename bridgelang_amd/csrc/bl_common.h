@@ -1,0 +1,49 @@
+// bl_common.h — device-side helpers shared by the gfx950 kernels (wave64, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/bridgelang_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;     // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;  // 16-byte vector
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;  // 8-byte vector
+
+#define BL_WAVE 64
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// ---- bf16 <-> fp32 ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+// Plain cast lowers to v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN-preserving) on gfx950.
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }  // round through bf16
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bflo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bfhi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// ---- wave reductions (xor butterfly over 64 lanes) ------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- activation functions, written so the CPU oracle can restate them op for op --------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+// ---- launch helpers -------------------------------------------------------------------------------------------
+#define BL_CHECK_LAUNCH()                                   \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return BL_E_LAUNCH;              \
+  } while (0)
+
+static inline bool bl_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

@@ -1,0 +1,92 @@
+// gemm_common.h — argument block and fused epilogues shared by the tiled GEMM (gemm_bf16.hip) and the skinny
+// weight-streaming GEMM (gemm_skinny.hip). Both kernels compute the MFMA tile TRANSPOSED, so a lane owns 4 consecutive
+// output columns n..n+3 of one row m; the epilogue below is written for that layout.
+#pragma once
+#include "bl_common.h"
+
+namespace blgemm {
+
+struct GemmArgs {
+  const uint16_t* A; const uint16_t* W; void* C;
+  const uint16_t* bias; const uint16_t* scale; const uint16_t* res;
+  long lda, ldw, ldc, ldres;
+  int M, N, K;
+  int res_row_mod, out_group, out_stride, out_offset;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int out_row_of(const GemmArgs& p, int m) {
+  if (p.out_group == 0) return m;
+  const int g = m / p.out_group, r = m - g * p.out_group + p.out_offset;
+  if (r < 0 || r >= p.out_stride) return -1;
+  return g * p.out_stride + r;
+}
+
+// Epilogue for one lane's 4 consecutive columns n..n+3 of row m.
+template <int EPI>
+__device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n, f32x4_t acc) {
+  if (m >= p.M || n >= p.N) return;
+  const int orow = out_row_of(p, m);
+  if (orow < 0) return;
+  if constexpr (EPI == BL_EPI_F32 || EPI == BL_EPI_F32_BF16R) {
+    float* c = (float*)p.C + (long)orow * p.ldc + n;
+    if constexpr (EPI == BL_EPI_F32_BF16R) acc = (f32x4_t){rbf(acc[0]), rbf(acc[1]), rbf(acc[2]), rbf(acc[3])};
+    *(f32x4_t*)c = acc;
+    return;
+  } else if constexpr (EPI == BL_EPI_SWIGLU) {
+    // rows 2j / 2j+1 of W are gate_j / up_j → regs (0,1) and (2,3) are (gate, up) pairs
+    const float g0 = rbf(acc[0]), u0 = rbf(acc[1]), g1 = rbf(acc[2]), u1 = rbf(acc[3]);
+    const float s0 = rbf(silu_f(g0)), s1 = rbf(silu_f(g1));
+    uint16_t* c = (uint16_t*)p.C + (long)orow * p.ldc + (n >> 1);
+    *(uint32_t*)c = pack2bf(s0 * u0, s1 * u1);
+    return;
+  } else {
+    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    if constexpr (EPI == BL_EPI_BIAS || EPI == BL_EPI_BIAS_GELU || EPI == BL_EPI_BIAS_RES) {
+      const u32x2_t b = *(const u32x2_t*)(p.bias + n);
+      v[0] += bflo(b[0]); v[1] += bfhi(b[0]); v[2] += bflo(b[1]); v[3] += bfhi(b[1]);
+    }
+    if constexpr (EPI == BL_EPI_BIAS_GELU) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = gelu_erf(rbf(v[i]));
+    }
+    if constexpr (EPI == BL_EPI_BIAS_RES || EPI == BL_EPI_RES) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = rbf(v[i]);
+      if (EPI == BL_EPI_BIAS_RES && p.scale != nullptr) {
+        const u32x2_t s = *(const u32x2_t*)(p.scale + n);
+        v[0] = rbf(v[0] * bflo(s[0])); v[1] = rbf(v[1] * bfhi(s[0]));
+        v[2] = rbf(v[2] * bflo(s[1])); v[3] = rbf(v[3] * bfhi(s[1]));
+      }
+      const int rrow = p.res_row_mod ? (m % p.res_row_mod) : m;
+      const u32x2_t r = *(const u32x2_t*)(p.res + (long)rrow * p.ldres + n);
+      v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]);
+    }
+    uint16_t* c = (uint16_t*)p.C + (long)orow * p.ldc + n;
+    u32x2_t o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+    *(u32x2_t*)c = o;
+  }
+}
+
+
+// host side: validate a descriptor and copy it into the device argument block
+inline int fill_gemm_args(const bl_gemm_desc* d, GemmArgs& a) {
+  if (!d || !d->A || !d->W || !d->C) return BL_E_ARG;
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % 64) != 0 || (d->N % 16) != 0) return BL_E_SHAPE;
+  if ((d->lda % 8) || (d->ldw % 8) || d->lda < d->K || d->ldw < d->K) return BL_E_ALIGN;
+  if (!bl_aligned16(d->A) || !bl_aligned16(d->W) || (((uintptr_t)d->C) & 15)) return BL_E_ALIGN;
+  const int epi = d->epilogue;
+  if (epi == BL_EPI_SWIGLU) { if ((d->ldc % 2) || (d->N % 32)) return BL_E_ALIGN; }
+  else if (d->ldc % 4) return BL_E_ALIGN;
+  if ((epi == BL_EPI_BIAS || epi == BL_EPI_BIAS_GELU || epi == BL_EPI_BIAS_RES) && !d->bias) return BL_E_ARG;
+  if ((epi == BL_EPI_BIAS_RES || epi == BL_EPI_RES) && (!d->res || (d->ldres % 4))) return BL_E_ARG;
+  if (d->out_group < 0 || (d->out_group > 0 && d->out_stride <= 0)) return BL_E_SHAPE;
+  a.A = d->A; a.W = d->W; a.C = d->C; a.bias = d->bias; a.scale = d->scale; a.res = d->res;
+  a.lda = d->lda; a.ldw = d->ldw; a.ldc = d->ldc; a.ldres = d->ldres;
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.res_row_mod = d->res_row_mod; a.out_group = d->out_group; a.out_stride = d->out_stride; a.out_offset = d->out_offset;
+  a.tiles_m = a.tiles_n = 0;
+  return BL_OK;
+}
+
+}  // namespace blgemm

@@ -1,0 +1,238 @@
+// glue.hip — small HBM-bound kernels around the GEMMs: synthetic tensor fill, RoPE + KV-cache append, embedding
+// gather for the multimodal splice, fp32 argmax, 14x14 im2col, prefix-token broadcast. All use 16-byte vector
+// accesses along the contiguous dimension.
+#include "bl_common.h"
+
+namespace bl_glue_impl {
+
+// ---- synthetic tensors: integer hash → Irwin-Hall(4) → two exactly-rounded fp32 ops. oracle/synth.py restates this
+// bit for bit in numpy, so the CPU oracle and the GPU hold identical weights without any host↔device copy. ----
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint16_t synth_value(uint32_t seed, uint32_t idx, float mean, float scale) {
+  const uint32_t h1 = mix32(idx ^ mix32(seed));
+  const uint32_t h2 = mix32(h1 + 0x9e3779b9u);
+  const int s = (int)((h1 & 0xffffu) + (h1 >> 16) + (h2 & 0xffffu) + (h2 >> 16)) - 131070;
+  const float v = __fadd_rn(mean, __fmul_rn((float)s, scale));   // no FMA contraction: matches numpy
+  return f2bf(v);
+}
+
+__global__ void fill_synth_kernel(uint16_t* dst, long rows, long cols, long ld, uint32_t seed, float mean,
+                                  float scale) {
+  const long total = rows * cols;   // logical elements only: pad columns [cols, ld) are left untouched
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols, c = i - r * cols;
+    dst[r * ld + c] = synth_value(seed, (uint32_t)i, mean, scale);
+  }
+}
+
+// ---- RoPE + KV-cache append. One thread per (token, head, 8 rotation pairs). ----
+// HF apply_rotary_pos_emb in bf16: q' = bf16(bf16(q*cos) + bf16(rotate_half(q)*sin)), rotate_half = cat(-x2, x1).
+__global__ void rope_kvcache_kernel(uint16_t* qkv, int B, int S, int H, int hd, const uint16_t* cos_tab,
+                                    const uint16_t* sin_tab, int pos0, uint16_t* k_cache, uint16_t* v_cache,
+                                    int cache_len) {
+  const int half = hd >> 1, cpr = half >> 3;          // 16-byte chunks per half head
+  const long total = (long)B * S * H * cpr;
+  const long D = (long)H * hd;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cpr);
+    const int h = (int)((i / cpr) % H);
+    const long tok = i / ((long)cpr * H);
+    const int s = (int)(tok % S), b = (int)(tok / S);
+    const int pos = pos0 + s;
+    const u32x4_t cq = *(const u32x4_t*)(cos_tab + (long)pos * half + ch * 8);
+    const u32x4_t sq = *(const u32x4_t*)(sin_tab + (long)pos * half + ch * 8);
+    uint16_t* row = qkv + tok * 3 * D;
+    const long cache_off = (((long)b * H + h) * cache_len + pos) * hd;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {             // 0 = q (in place), 1 = k (→ cache)
+      uint16_t* src = row + part * D + (long)h * hd;
+      const u32x4_t x1 = *(const u32x4_t*)(src + ch * 8);
+      const u32x4_t x2 = *(const u32x4_t*)(src + half + ch * 8);
+      u32x4_t o1, o2;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        float r1[2], r2[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float a = e ? bfhi(x1[w]) : bflo(x1[w]);
+          const float c2 = e ? bfhi(x2[w]) : bflo(x2[w]);
+          const float co = e ? bfhi(cq[w]) : bflo(cq[w]);
+          const float si = e ? bfhi(sq[w]) : bflo(sq[w]);
+          r1[e] = rbf(a * co) + rbf(-c2 * si);          // first half:  x1*cos + (-x2)*sin
+          r2[e] = rbf(c2 * co) + rbf(a * si);           // second half: x2*cos + x1*sin
+        }
+        o1[w] = pack2bf(r1[0], r1[1]);
+        o2[w] = pack2bf(r2[0], r2[1]);
+      }
+      uint16_t* dst = part == 0 ? src : (k_cache + cache_off);
+      *(u32x4_t*)(dst + ch * 8) = o1;
+      *(u32x4_t*)(dst + half + ch * 8) = o2;
+    }
+    // v: plain copy into the cache (two chunks per thread cover the head together with the other threads)
+    const uint16_t* vsrc = row + 2 * D + (long)h * hd;
+    uint16_t* vdst = v_cache + cache_off;
+    *(u32x4_t*)(vdst + ch * 8) = *(const u32x4_t*)(vsrc + ch * 8);
+    *(u32x4_t*)(vdst + half + ch * 8) = *(const u32x4_t*)(vsrc + half + ch * 8);
+  }
+}
+
+// ---- embedding gather for the multimodal splice ----
+__global__ void embed_splice_kernel(const int64_t* ids, int B, int L, const uint16_t* table, int dim, int n_patches,
+                                    uint16_t* dst) {
+  const int cpr = dim >> 3;
+  const long total = (long)B * L * cpr;
+  const int S = L + n_patches;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cpr);
+    const long t = i / cpr;
+    const int j = (int)(t % L), b = (int)(t / L);
+    const long id = ids[(long)b * L + j];
+    const int orow = (j == 0) ? 0 : j + n_patches;
+    *(u32x4_t*)(dst + ((long)b * S + orow) * dim + ch * 8) = *(const u32x4_t*)(table + id * dim + ch * 8);
+  }
+}
+
+// ---- argmax over fp32 rows; ties → lowest index (torch.argmax) ----
+__global__ __launch_bounds__(256) void argmax_kernel(const float* logits, long ld, int n, int64_t* out) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const float* row = logits + (long)blockIdx.x * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x * 4; i < n; i += 256 * 4) {
+    const f32x4_t q = *(const f32x4_t*)(row + i);     // n % 4 == 0 checked on the host
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (q[e] > best || (q[e] == best && i + e < bi)) { best = q[e]; bi = i + e; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sv[wave] = best; si[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    out[blockIdx.x] = (int64_t)bi;
+  }
+}
+
+// ---- 14×14 patch im2col (stride 14) for one 3-channel tower; K padded to ld ≥ 588 with zeros ----
+// One thread per (patch, channel, patch-row i): 14 contiguous pixels = 28 B in, 28 B out.
+__global__ void im2col_patch14_kernel(const uint16_t* pv, int B, int chan0, uint16_t* out, long ld) {
+  const long total = (long)B * 256 * 42;   // 3 channels × 14 rows
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(t % 42), c = ci / 14, i = ci % 14;
+    const long pb = t / 42;
+    const int p = (int)(pb % 256), b = (int)(pb / 256);
+    const int py = p >> 4, px = p & 15;
+    const uint16_t* src = pv + (((long)b * 6 + chan0 + c) * 224 + py * 14 + i) * 224 + px * 14;
+    uint16_t* dst = out + ((long)b * 256 + p) * ld + c * 196 + i * 14;
+#pragma unroll
+    for (int j = 0; j < 14; j += 2) *(uint32_t*)(dst + j) = *(const uint32_t*)(src + j);   // 4-byte aligned: all offsets even
+    if (ci == 0)
+      for (long z = 588; z < ld; z += 2) *(uint32_t*)(out + ((long)b * 256 + p) * ld + z) = 0u;
+  }
+}
+
+__global__ void write_prefix_kernel(const uint16_t* prefix, int n_prefix, int dim, uint16_t* x, int B, int T) {
+  const int cpr = dim >> 3;
+  const long total = (long)B * n_prefix * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cpr);
+    const long t = i / cpr;
+    const int j = (int)(t % n_prefix), b = (int)(t / n_prefix);
+    *(u32x4_t*)(x + ((long)b * T + j) * dim + ch * 8) = *(const u32x4_t*)(prefix + (long)j * dim + ch * 8);
+  }
+}
+
+inline int grid_for(long total, int block) {
+  long g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));   // cap at 256 CUs × 8 and grid-stride the rest
+}
+
+}  // namespace bl_glue_impl
+using namespace bl_glue_impl;
+
+extern "C" int bl_abi_version(void) { return 1; }
+extern "C" const char* bl_build_arch(void) { return "gfx950"; }
+
+extern "C" int bl_fill_synth_bf16_2d(bl_bf16* dst, int64_t rows, int64_t cols, int64_t ld, uint32_t seed, float mean,
+                                     float scale, void* stream) {
+  if (!dst) return BL_E_ARG;
+  if (rows <= 0 || cols <= 0 || ld < cols || rows * cols > 0xffffffffLL) return BL_E_SHAPE;
+  hipLaunchKernelGGL(fill_synth_kernel, dim3(grid_for(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, dst,
+                     (long)rows, (long)cols, (long)ld, seed, mean, scale);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+extern "C" int bl_fill_synth_bf16(bl_bf16* dst, int64_t n, uint32_t seed, float mean, float scale, void* stream) {
+  return bl_fill_synth_bf16_2d(dst, 1, n, n, seed, mean, scale, stream);
+}
+
+extern "C" int bl_rope_kvcache_bf16(bl_bf16* qkv, int32_t B, int32_t S, int32_t H, int32_t hd, const bl_bf16* cos_tab,
+                                    const bl_bf16* sin_tab, int32_t pos0, bl_bf16* k_cache, bl_bf16* v_cache,
+                                    int32_t cache_len, void* stream) {
+  if (!qkv || !cos_tab || !sin_tab || !k_cache || !v_cache) return BL_E_ARG;
+  if (B <= 0 || S <= 0 || H <= 0 || hd <= 0 || (hd % 16) || pos0 < 0 || pos0 + S > cache_len) return BL_E_SHAPE;
+  if (!bl_aligned16(qkv) || !bl_aligned16(cos_tab) || !bl_aligned16(sin_tab) || !bl_aligned16(k_cache) ||
+      !bl_aligned16(v_cache))
+    return BL_E_ALIGN;
+  const long total = (long)B * S * H * (hd / 16);
+  hipLaunchKernelGGL(rope_kvcache_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, qkv, B, S, H,
+                     hd, cos_tab, sin_tab, pos0, k_cache, v_cache, cache_len);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_embed_splice_bf16(const int64_t* ids, int32_t B, int32_t L, const bl_bf16* table, int32_t dim,
+                                    int32_t n_patches, bl_bf16* dst, void* stream) {
+  if (!ids || !table || !dst) return BL_E_ARG;
+  if (B <= 0 || L <= 0 || dim <= 0 || (dim % 8) || n_patches < 0) return BL_E_SHAPE;
+  if (!bl_aligned16(table) || !bl_aligned16(dst)) return BL_E_ALIGN;
+  const long total = (long)B * L * (dim / 8);
+  hipLaunchKernelGGL(embed_splice_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, ids, B, L,
+                     table, dim, n_patches, dst);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_argmax_f32(const float* logits, int64_t ld, int32_t rows, int32_t n, int64_t* out, void* stream) {
+  if (!logits || !out) return BL_E_ARG;
+  if (rows <= 0 || n <= 0 || (n % 4) || (ld % 4)) return BL_E_SHAPE;
+  if (!bl_aligned16(logits)) return BL_E_ALIGN;
+  hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, n, out);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_im2col_patch14_bf16(const bl_bf16* pixel_values, int32_t B, int32_t chan0, bl_bf16* out, int64_t ld,
+                                      void* stream) {
+  if (!pixel_values || !out) return BL_E_ARG;
+  if (B <= 0 || (chan0 != 0 && chan0 != 3) || ld < 588 || (ld % 8)) return BL_E_SHAPE;
+  if ((((uintptr_t)pixel_values) & 3) || !bl_aligned16(out)) return BL_E_ALIGN;
+  const long total = (long)B * 256 * 42;
+  hipLaunchKernelGGL(im2col_patch14_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     pixel_values, B, chan0, out, (long)ld);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_write_prefix_tokens_bf16(const bl_bf16* prefix, int32_t n_prefix, int32_t dim, bl_bf16* x, int32_t B,
+                                           int32_t T, void* stream) {
+  if (!prefix || !x) return BL_E_ARG;
+  if (n_prefix <= 0 || dim <= 0 || (dim % 8) || B <= 0 || T < n_prefix) return BL_E_SHAPE;
+  if (!bl_aligned16(prefix) || !bl_aligned16(x)) return BL_E_ALIGN;
+  const long total = (long)B * n_prefix * (dim / 8);
+  hipLaunchKernelGGL(write_prefix_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, prefix,
+                     n_prefix, dim, x, B, T);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}

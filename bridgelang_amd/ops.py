@@ -1,0 +1,265 @@
+"""Thin torch-tensor front end over the C ABI (bridgelang_amd/_lib.py → libbridgelang_hip.so).
+
+PyTorch is plumbing only: tensors give device memory and the current HIP stream; every arithmetic operation is a
+hand-written gfx950 kernel behind `bl_*`. Each builder returns an `Op` (a prepared C call whose descriptor structs are
+built once); `Op.run()` enqueues it on the current stream. The engine keeps lists of Ops and replays them (directly or
+under HIP-graph capture), so steady-state host cost is one ctypes call per kernel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (AttnDesc, GemmDesc, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_F32, EPI_F32_BF16R, EPI_NONE,
+                   EPI_RES, EPI_SWIGLU)
+
+__all__ = ["Op", "gemm", "layernorm", "rmsnorm", "attention", "attention_decode", "rope_kvcache", "embed_splice",
+           "argmax", "im2col_patch14", "write_prefix_tokens", "fill_synth", "run_all",
+           "EPI_NONE", "EPI_BIAS", "EPI_BIAS_GELU", "EPI_BIAS_RES", "EPI_RES", "EPI_SWIGLU", "EPI_F32", "EPI_F32_BF16R"]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _bf16(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.dtype != torch.bfloat16 or not t.is_cuda:
+        raise TypeError(f"{what}: expected a CUDA/HIP bfloat16 tensor, got {t.dtype} on {t.device}")
+    return t
+
+
+def _rows(t: torch.Tensor, what: str) -> int:
+    """Leading dimension (elements) of a 2-D view whose last dim is contiguous."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{what}: expected a 2-D tensor with contiguous last dim, got shape {tuple(t.shape)} "
+                         f"stride {t.stride()}")
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+class Op:
+    """A prepared call into libbridgelang_hip.so. Keeps its tensors alive."""
+    __slots__ = ("name", "fn", "args", "keep")
+
+    def __init__(self, name: str, fn, args: tuple, keep: tuple):
+        self.name, self.fn, self.args, self.keep = name, fn, args, keep
+
+    def run(self, stream: Optional[int] = None) -> None:
+        rc = self.fn(*self.args, stream if stream is not None else _stream())
+        if rc != 0:
+            _lib.check(rc, self.name)
+
+
+def run_all(ops: Sequence[Op]) -> None:
+    s = _stream()
+    for op in ops:
+        rc = op.fn(*op.args, s)
+        if rc != 0:
+            _lib.check(rc, op.name)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, *,
+         bias: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
+         res: Optional[torch.Tensor] = None, res_row_mod: int = 0,
+         out_map: Optional[Tuple[int, int, int]] = None, N: Optional[int] = None,
+         skinny: Optional[bool] = None, run: bool = True) -> Op:
+    """out = epilogue(A @ W.T).  A [M,K], W [N,K] (nn.Linear layout), out [rows, N] (N/2 for SWIGLU; fp32 for F32).
+
+    `out_map=(group, stride, offset)` remaps output rows (see bl_gemm_desc). `N` restricts to the first N weight rows.
+    `skinny=None` picks the weight-streaming kernel automatically for M <= 16 when it supports K.
+    """
+    lib = _lib.load()
+    _bf16(A, "A"); _bf16(W, "W")
+    M, K = A.shape
+    n_rows, Kw = W.shape
+    if Kw != K:
+        raise ValueError(f"gemm: K mismatch A{tuple(A.shape)} W{tuple(W.shape)}")
+    N = n_rows if N is None else N
+    want = torch.float32 if epilogue in (EPI_F32, EPI_F32_BF16R) else torch.bfloat16
+    if out.dtype != want or not out.is_cuda:
+        raise TypeError(f"gemm: out must be {want} on device")
+    d = GemmDesc()
+    d.A, d.lda = A.data_ptr(), _rows(A, "A")
+    d.W, d.ldw = W.data_ptr(), _rows(W, "W")
+    d.C, d.ldc = out.data_ptr(), _rows(out, "out")
+    d.M, d.N, d.K, d.epilogue = M, N, K, epilogue
+    keep = [A, W, out]
+    if bias is not None:
+        d.bias = _bf16(bias, "bias").data_ptr(); keep.append(bias)
+    if scale is not None:
+        d.scale = _bf16(scale, "scale").data_ptr(); keep.append(scale)
+    if res is not None:
+        d.res, d.ldres = _bf16(res, "res").data_ptr(), _rows(res, "res"); keep.append(res)
+    d.res_row_mod = res_row_mod
+    if out_map is not None:
+        d.out_group, d.out_stride, d.out_offset = out_map
+    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    if out.shape[1] < n_out:
+        raise ValueError(f"gemm: out has {out.shape[1]} columns, needs {n_out}")
+    rows_needed = M if out_map is None else ((M - 1) // out_map[0]) * out_map[1] + min(out_map[1], out_map[0] + out_map[2])
+    if out.shape[0] < rows_needed and out_map is None:
+        raise ValueError(f"gemm: out has {out.shape[0]} rows, needs {rows_needed}")
+    use_skinny = skinny
+    if use_skinny is None:
+        use_skinny = (M <= 16 and K in (512, 1024, 1536, 4096, 5120, 11008, 13824)
+                      and epilogue in (EPI_NONE, EPI_RES, EPI_SWIGLU, EPI_F32, EPI_F32_BF16R))
+    fn = lib.bl_gemm_skinny_bf16 if use_skinny else lib.bl_gemm_bf16
+    op = Op("bl_gemm_skinny_bf16" if use_skinny else "bl_gemm_bf16", fn, (C.byref(d),), (d, *keep))
+    if run:
+        op.run()
+    return op
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, eps: float = 1e-6,
+              run: bool = True) -> Op:
+    lib = _lib.load()
+    _bf16(x, "x"); _bf16(out, "out")
+    rows, dim = x.shape
+    op = Op("bl_layernorm_bf16", lib.bl_layernorm_bf16,
+            (x.data_ptr(), _rows(x, "x"), _bf16(w, "w").data_ptr(), _bf16(b, "b").data_ptr(), out.data_ptr(),
+             _rows(out, "out"), rows, dim, float(eps)), (x, w, b, out))
+    if run:
+        op.run()
+    return op
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, eps: float = 1e-6, run: bool = True) -> Op:
+    lib = _lib.load()
+    _bf16(x, "x"); _bf16(out, "out")
+    rows, dim = x.shape
+    op = Op("bl_rmsnorm_bf16", lib.bl_rmsnorm_bf16,
+            (x.data_ptr(), _rows(x, "x"), _bf16(w, "w").data_ptr(), out.data_ptr(), _rows(out, "out"), rows, dim,
+             float(eps)), (x, w, out))
+    if run:
+        op.run()
+    return op
+
+
+def _attn_desc(q, k, v, o, B, H, Sq, Skv, hd, q_str, k_str, v_str, o_str, causal, scale, key_mask):
+    d = AttnDesc()
+    d.q, (d.q_bs, d.q_hs, d.q_rs) = _bf16(q, "q").data_ptr(), q_str
+    d.k, (d.k_bs, d.k_hs, d.k_rs) = _bf16(k, "k").data_ptr(), k_str
+    d.v, (d.v_bs, d.v_hs, d.v_rs) = _bf16(v, "v").data_ptr(), v_str
+    d.o, (d.o_bs, d.o_hs, d.o_rs) = _bf16(o, "o").data_ptr(), o_str
+    if key_mask is not None:
+        if key_mask.dtype != torch.uint8 or key_mask.dim() != 2 or key_mask.stride(1) != 1:
+            raise TypeError("key_mask must be a [B, Skv] uint8 tensor")
+        d.key_mask, d.mask_bs = key_mask.data_ptr(), key_mask.stride(0)
+    d.B, d.H, d.Sq, d.Skv, d.head_dim, d.causal, d.scale = B, H, Sq, Skv, hd, int(causal), float(scale)
+    return d
+
+
+def attention(q, k, v, o, *, B: int, H: int, Sq: int, Skv: int, head_dim: int, q_strides, k_strides, v_strides,
+              o_strides, causal: bool, scale: Optional[float] = None, key_mask: Optional[torch.Tensor] = None,
+              run: bool = True) -> Op:
+    """Flash attention over strided [batch, head, row, head_dim] views; strides are (batch, head, row) in elements."""
+    lib = _lib.load()
+    scale = head_dim ** -0.5 if scale is None else scale
+    d = _attn_desc(q, k, v, o, B, H, Sq, Skv, head_dim, q_strides, k_strides, v_strides, o_strides, causal, scale,
+                   key_mask)
+    op = Op("bl_attention_bf16", lib.bl_attention_bf16, (C.byref(d),), (d, q, k, v, o, key_mask))
+    if run:
+        op.run()
+    return op
+
+
+def attention_decode(q, k, v, o, *, B: int, H: int, Skv: int, head_dim: int, q_strides, k_strides, v_strides,
+                     o_strides, scale: Optional[float] = None, key_mask: Optional[torch.Tensor] = None,
+                     run: bool = True) -> Op:
+    lib = _lib.load()
+    scale = head_dim ** -0.5 if scale is None else scale
+    d = _attn_desc(q, k, v, o, B, H, 1, Skv, head_dim, q_strides, k_strides, v_strides, o_strides, False, scale,
+                   key_mask)
+    op = Op("bl_attention_decode_bf16", lib.bl_attention_decode_bf16, (C.byref(d),), (d, q, k, v, o, key_mask))
+    if run:
+        op.run()
+    return op
+
+
+def rope_kvcache(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, k_cache: torch.Tensor,
+                 v_cache: torch.Tensor, *, B: int, S: int, H: int, head_dim: int, pos0: int, run: bool = True) -> Op:
+    """qkv [B*S, 3*H*hd] (q rotated in place); caches [B, H, cache_len, hd]; cos/sin [max_pos, hd/2] bf16."""
+    lib = _lib.load()
+    for t, n in ((qkv, "qkv"), (cos, "cos"), (sin, "sin"), (k_cache, "k_cache"), (v_cache, "v_cache")):
+        _bf16(t, n)
+        if not t.is_contiguous():
+            raise ValueError(f"rope_kvcache: {n} must be contiguous")
+    cache_len = k_cache.shape[2]
+    if pos0 + S > cos.shape[0]:
+        raise ValueError("rope_kvcache: position exceeds the cos/sin table")
+    op = Op("bl_rope_kvcache_bf16", lib.bl_rope_kvcache_bf16,
+            (qkv.data_ptr(), B, S, H, head_dim, cos.data_ptr(), sin.data_ptr(), pos0, k_cache.data_ptr(),
+             v_cache.data_ptr(), cache_len), (qkv, cos, sin, k_cache, v_cache))
+    if run:
+        op.run()
+    return op
+
+
+def embed_splice(ids: torch.Tensor, table: torch.Tensor, dst: torch.Tensor, n_patches: int, run: bool = True) -> Op:
+    """dst[b,0] = table[ids[b,0]]; dst[b, 1+n_patches+j] = table[ids[b,1+j]].  ids int64 [B,L]; dst [B, L+n_patches, D]."""
+    lib = _lib.load()
+    if ids.dtype != torch.int64 or not ids.is_contiguous():
+        raise TypeError("ids must be a contiguous int64 tensor")
+    B, L = ids.shape
+    dim = table.shape[1]
+    if tuple(dst.shape) != (B, L + n_patches, dim) or not dst.is_contiguous():
+        raise ValueError(f"embed_splice: dst must be contiguous [{B}, {L + n_patches}, {dim}]")
+    op = Op("bl_embed_splice_bf16", lib.bl_embed_splice_bf16,
+            (ids.data_ptr(), B, L, _bf16(table, "table").data_ptr(), dim, n_patches, _bf16(dst, "dst").data_ptr()),
+            (ids, table, dst))
+    if run:
+        op.run()
+    return op
+
+
+def argmax(logits: torch.Tensor, out: torch.Tensor, run: bool = True) -> Op:
+    lib = _lib.load()
+    if logits.dtype != torch.float32 or out.dtype != torch.int64:
+        raise TypeError("argmax: logits fp32 [rows, n], out int64 [rows]")
+    rows, n = logits.shape
+    op = Op("bl_argmax_f32", lib.bl_argmax_f32, (logits.data_ptr(), _rows(logits, "logits"), rows, n, out.data_ptr()),
+            (logits, out))
+    if run:
+        op.run()
+    return op
+
+
+def im2col_patch14(pixel_values: torch.Tensor, chan0: int, out: torch.Tensor, run: bool = True) -> Op:
+    """pixel_values [B,6,224,224] bf16 → out [B*256, ld>=588] patch rows of channels chan0..chan0+2."""
+    lib = _lib.load()
+    _bf16(pixel_values, "pixel_values"); _bf16(out, "out")
+    if tuple(pixel_values.shape[1:]) != (6, 224, 224) or not pixel_values.is_contiguous():
+        raise ValueError("im2col_patch14: pixel_values must be contiguous [B, 6, 224, 224]")
+    B = pixel_values.shape[0]
+    op = Op("bl_im2col_patch14_bf16", lib.bl_im2col_patch14_bf16,
+            (pixel_values.data_ptr(), B, chan0, out.data_ptr(), _rows(out, "out")), (pixel_values, out))
+    if run:
+        op.run()
+    return op
+
+
+def write_prefix_tokens(prefix: torch.Tensor, x: torch.Tensor, B: int, T: int, run: bool = True) -> Op:
+    lib = _lib.load()
+    n_prefix, dim = prefix.shape
+    op = Op("bl_write_prefix_tokens_bf16", lib.bl_write_prefix_tokens_bf16,
+            (_bf16(prefix, "prefix").data_ptr(), n_prefix, dim, _bf16(x, "x").data_ptr(), B, T), (prefix, x))
+    if run:
+        op.run()
+    return op
+
+
+def fill_synth(dst: torch.Tensor, seed: int, mean: float, scale: float, *, rows: Optional[int] = None,
+               cols: Optional[int] = None, ld: Optional[int] = None, run: bool = True) -> Op:
+    """Deterministic synthetic fill (see oracle/synth.py for the CPU restatement of the same generator)."""
+    lib = _lib.load()
+    _bf16(dst, "dst")
+    if rows is None:
+        rows, cols, ld = 1, dst.numel(), dst.numel()
+    op = Op("bl_fill_synth_bf16_2d", lib.bl_fill_synth_bf16_2d,
+            (dst.data_ptr(), rows, cols, ld, seed & 0xFFFFFFFF, float(mean), float(scale)), (dst,))
+    if run:
+        op.run()
+    return op

@@ -1,0 +1,144 @@
+/*
+ * bridgelang_hip.h — C ABI of libbridgelang_hip.so (gfx950 / MI355X).
+ *
+ * The reference (CliffKai/BridgeLang, a thin OpenVLA fork) has no C ABI of its own: its hot path is Python that
+ * calls timm / transformers / flash-attn / torch. The drop-in seam is therefore the Python classes
+ * in bridgelang_amd/extern/hf/modeling_prismatic.py; *behind* that seam every arithmetic operation goes through the
+ * entry points declared here. Each entry point cites the reference call site whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain pointers (device memory) and integer sizes only; no torch / C++ types cross the boundary
+ *   - every function enqueues work on `stream` (a hipStream_t passed as void*) and returns immediately
+ *   - no allocation, no host synchronisation, no global mutable state (thread-compatible, graph-capturable)
+ *   - return value: 0 = ok, negative = error (BL_E_*); nothing is thrown across the ABI
+ *   - bf16 tensors are raw uint16 bit patterns (`bl_bf16`); row-major; strides in ELEMENTS
+ */
+#ifndef BRIDGELANG_HIP_H
+#define BRIDGELANG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t bl_bf16;
+
+#define BL_OK 0
+#define BL_E_SHAPE (-1)   /* unsupported / inconsistent shape        */
+#define BL_E_ALIGN (-2)   /* pointer or stride alignment not met     */
+#define BL_E_LAUNCH (-3)  /* hipLaunchKernel reported an error       */
+#define BL_E_ARG (-4)     /* null pointer / bad enum                 */
+
+/* ---- library info ------------------------------------------------------------------------------------------- */
+int bl_abi_version(void);          /* bumps when a signature changes */
+const char* bl_build_arch(void);   /* "gfx950" */
+
+/* ---- deterministic synthetic tensors ------------------------------------------------------------------------ */
+/* Fills dst[i] = bf16(mean + scale * irwin_hall4(seed, i)) — bit-identical to oracle/synth.py (integer hash +
+ * two exactly-rounded fp32 ops). Stands in for `from_pretrained` weights (no checkpoint exists offline): the
+ * reference initialises with normal(0, initializer_range), prismatic/extern/hf/modeling_prismatic.py:185-205. */
+int bl_fill_synth_bf16(bl_bf16* dst, int64_t n, uint32_t seed, float mean, float scale, void* stream);
+/* Same generator for a [rows, cols] logical matrix stored with leading dimension ld >= cols: element (r, c) gets the
+ * value of logical index r*cols + c, so padded / interleaved device layouts hold the same numbers as the unpadded
+ * tensor. Columns [cols, ld) are NOT written (allocate zeroed). */
+int bl_fill_synth_bf16_2d(bl_bf16* dst, int64_t rows, int64_t cols, int64_t ld, uint32_t seed, float mean,
+                          float scale, void* stream);
+
+/* ---- GEMM: C[M,N] = epilogue(A[M,K] * W[N,K]^T) ------------------------------------------------------------- */
+/* Replaces every nn.Linear on the path: timm Attention.qkv/proj + Mlp.fc1/fc2 (created at
+ * modeling_prismatic.py:78-101), PrismaticProjector fc1/fc2/fc3 (modeling_prismatic.py:146-158), and the HF Llama
+ * q/k/v/o/gate/up/down projections + lm_head (built at modeling_prismatic.py:248-250). fp32 accumulate on MFMA;
+ * rounding points follow the bf16 reference (output of each Linear rounded to bf16 before the next elementwise op). */
+enum bl_epilogue {
+  BL_EPI_NONE = 0,        /* C = bf16(acc)                                                              */
+  BL_EPI_BIAS = 1,        /* C = bf16(acc + bias[n])                                                    */
+  BL_EPI_BIAS_GELU = 2,   /* t = bf16(acc + bias[n]);  C = bf16(gelu_erf(t))                            */
+  BL_EPI_BIAS_RES = 3,    /* t = bf16(acc + bias[n]);  [t = bf16(t*scale[n])];  C = bf16(res + t)       */
+  BL_EPI_RES = 4,         /* t = bf16(acc);            C = bf16(res + t)                                */
+  BL_EPI_SWIGLU = 5,      /* W rows interleaved (2j = gate_j, 2j+1 = up_j); C[m, j] = silu(g)*u, N/2 wide */
+  BL_EPI_F32 = 6,         /* C = acc  (fp32 output)                                                     */
+  BL_EPI_F32_BF16R = 7    /* C = (float)bf16(acc): HF `lm_head(h).float()` — logits are bf16 values upcast     */
+};
+
+typedef struct bl_gemm_desc {
+  const bl_bf16* A;  int64_t lda;      /* [M, K] activations                                                  */
+  const bl_bf16* W;  int64_t ldw;      /* [N, K] weights (nn.Linear layout)                                   */
+  void* C;           int64_t ldc;      /* [M, N] (or [M, N/2] for SWIGLU); bf16, or fp32 for BL_EPI_F32*      */
+  int32_t M, N, K;                     /* K % 64 == 0 (pad in HBM), N % 16 == 0                               */
+  int32_t epilogue;                    /* enum bl_epilogue                                                    */
+  const bl_bf16* bias;                 /* [N] or NULL                                                         */
+  const bl_bf16* scale;                /* [N] LayerScale (modeling_prismatic.py:52-59) or NULL                */
+  const bl_bf16* res; int64_t ldres;   /* residual / additive table; row = res_row_mod ? m % res_row_mod : m  */
+  int32_t res_row_mod;
+  /* output-row remap: out_row = (m / out_group) * out_stride + (m % out_group) + out_offset; rows whose
+   * (m % out_group) + out_offset falls outside [0, out_stride) are dropped. out_group == 0 → identity.
+   * Used to write patch-embeddings behind the cls/register tokens, to strip prefix tokens at the ViT tap
+   * (modeling_prismatic.py:85-87,121-123) and to write projector output straight into LLM embedding rows 1..256
+   * (modeling_prismatic.py:383-385). */
+  int32_t out_group, out_stride, out_offset;
+} bl_gemm_desc;
+
+int bl_gemm_bf16(const bl_gemm_desc* d, void* stream);
+
+/* Skinny GEMM for M <= 16 rows (decode steps and last-row lm_head): weight-streaming, HBM-bound.
+ * Supports BL_EPI_NONE / BL_EPI_RES / BL_EPI_SWIGLU / BL_EPI_F32 / BL_EPI_F32_BF16R. Replaces the same nn.Linear modules on the
+ * cached-decode branch (modeling_prismatic.py:325-341). */
+int bl_gemm_skinny_bf16(const bl_gemm_desc* d, void* stream);
+
+/* ---- normalisation ------------------------------------------------------------------------------------------ */
+/* timm Block.norm1/norm2: LayerNorm(eps, affine), fp32 statistics, bf16 out. y may alias x. */
+int bl_layernorm_bf16(const bl_bf16* x, int64_t ldx, const bl_bf16* w, const bl_bf16* b, bl_bf16* y, int64_t ldy,
+                      int32_t rows, int32_t dim, float eps, void* stream);
+/* HF LlamaRMSNorm: t = bf16(x * rsqrt(mean(x^2) + eps)); y = bf16(w * t). */
+int bl_rmsnorm_bf16(const bl_bf16* x, int64_t ldx, const bl_bf16* w, bl_bf16* y, int64_t ldy, int32_t rows,
+                    int32_t dim, float eps, void* stream);
+
+/* ---- attention ---------------------------------------------------------------------------------------------- */
+/* Flash-style softmax(q k^T * scale [+ causal] [+ key mask]) v, fp32 scores/softmax, bf16 P for the PV product.
+ * Replaces timm Attention (SDPA, non-causal, head_dim 64 / 72) and HF LlamaAttention prefill (causal, head_dim 128;
+ * the reference callers hard-wire flash_attention_2 / sdpa: deploy.py:67, run_openvla_demo.py:25).
+ * Element strides: *_bs batch, *_hs head, *_rs row (token). head_dim contiguous. key_mask: [B, Skv] uint8 or NULL. */
+typedef struct bl_attn_desc {
+  const bl_bf16* q; int64_t q_bs, q_hs, q_rs;
+  const bl_bf16* k; int64_t k_bs, k_hs, k_rs;
+  const bl_bf16* v; int64_t v_bs, v_hs, v_rs;
+  bl_bf16* o;       int64_t o_bs, o_hs, o_rs;
+  const uint8_t* key_mask; int64_t mask_bs;
+  int32_t B, H, Sq, Skv, head_dim;
+  int32_t causal;      /* 1: key j visible to query i iff j <= i + (Skv - Sq) */
+  float scale;         /* head_dim^-0.5 */
+} bl_attn_desc;
+int bl_attention_bf16(const bl_attn_desc* d, void* stream);
+/* Single-query decode attention over a KV cache; kv_len = number of valid keys (same for the whole batch). */
+int bl_attention_decode_bf16(const bl_attn_desc* d, void* stream);
+
+/* ---- Llama glue -------------------------------------------------------------------------------------------- */
+/* Half-split RoPE (HF apply_rotary_pos_emb) on the q and k thirds of a fused qkv buffer [B*S, 3*H*hd], bf16 cos/sin
+ * tables [max_pos, hd/2] (built on the host exactly as HF does: fp32 trig → bf16). q is rotated in place; rotated k
+ * and v are appended to the KV cache [B, H, cache_len, hd] at positions pos0 .. pos0+S-1. */
+int bl_rope_kvcache_bf16(bl_bf16* qkv, int32_t B, int32_t S, int32_t H, int32_t hd, const bl_bf16* cos_tab,
+                         const bl_bf16* sin_tab, int32_t pos0, bl_bf16* k_cache, bl_bf16* v_cache,
+                         int32_t cache_len, void* stream);
+/* Token-embedding gather for the multimodal splice (modeling_prismatic.py:380-385): writes
+ * dst[b, 0] = table[ids[b,0]] and dst[b, 1+n_patches+j] = table[ids[b,1+j]]; rows 1..n_patches are left for the
+ * projector epilogue. ids int64 [B, L]; dst [B, L+n_patches, dim]. With n_patches = 0 it is a plain gather. */
+int bl_embed_splice_bf16(const int64_t* ids, int32_t B, int32_t L, const bl_bf16* table, int32_t dim,
+                         int32_t n_patches, bl_bf16* dst, void* stream);
+/* Row-wise argmax of fp32 logits [rows, n] (first maximal index, as torch.argmax); out int64 [rows]. */
+int bl_argmax_f32(const float* logits, int64_t ld, int32_t rows, int32_t n, int64_t* out, void* stream);
+
+/* ---- vision glue ------------------------------------------------------------------------------------------- */
+/* pixel_values [B, 6, 224, 224] bf16 (processing_prismatic.py:128-145 layout) → 14x14 patch rows for one tower:
+ * out[b*256 + py*16 + px, c*196 + i*14 + j] = pixel_values[b, chan0 + c, py*14 + i, px*14 + j]; columns 588..ld-1
+ * are zeroed (K padded to a multiple of 64 for the patch-embed GEMM; timm PatchEmbed conv flattening order). */
+int bl_im2col_patch14_bf16(const bl_bf16* pixel_values, int32_t B, int32_t chan0, bl_bf16* out, int64_t ld,
+                           void* stream);
+/* Broadcast `n_prefix` learned prefix tokens (cls + registers) into rows [b*T, b*T + n_prefix) of x [B*T, dim]. */
+int bl_write_prefix_tokens_bf16(const bl_bf16* prefix, int32_t n_prefix, int32_t dim, bl_bf16* x, int32_t B,
+                                int32_t T, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRIDGELANG_HIP_H */

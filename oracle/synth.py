@@ -1,0 +1,65 @@
+"""TEST INFRASTRUCTURE — CPU restatement of the deterministic synthetic-tensor generator.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package; the product
+(bridgelang_amd/) never does.
+
+Restates `synth_value` in bridgelang_amd/csrc/glue.hip bit for bit: a lowbias32 integer hash, the sum of four 16-bit
+uniforms (Irwin-Hall, approximately normal), one exactly-rounded fp32 multiply and one exactly-rounded fp32 add, then
+round-to-nearest-even to bf16. Because every step is integer arithmetic or a single IEEE operation, the GPU and the CPU
+produce identical bits, so the oracle and the HIP path can hold the same "checkpoint" without ever copying weights.
+
+There is no reference counterpart (the reference loads real checkpoints; none exists offline — SURVEY.md §8c); the
+distribution mirrors the reference's init, normal(0, initializer_range): modeling_prismatic.py:185-205.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict, Iterable, Tuple
+
+import numpy as np
+import torch
+
+IRWIN_HALL_SD = 37837.2265625
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def _mix32(x: np.ndarray) -> np.ndarray:
+    """lowbias32 on uint64 lanes masked to 32 bits (numpy has no wrapping uint32 multiply without warnings)."""
+    x = x & _M32
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & _M32
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & _M32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def tensor_seed(name: str, seed: int) -> int:
+    return (zlib.crc32(name.encode()) ^ ((seed * 0x9E3779B1) & 0xFFFFFFFF)) & 0xFFFFFFFF
+
+
+def synth_f32(n: int, seed32: int, mean: float, std: float, start: int = 0) -> np.ndarray:
+    """fp32 values (before the bf16 rounding) of logical elements start .. start+n-1."""
+    idx = np.arange(start, start + n, dtype=np.uint64)
+    sm = _mix32(np.array([seed32], dtype=np.uint64))[0]
+    h1 = _mix32(idx ^ sm)
+    h2 = _mix32((h1 + np.uint64(0x9E3779B9)) & _M32)
+    s = ((h1 & np.uint64(0xFFFF)) + (h1 >> np.uint64(16)) + (h2 & np.uint64(0xFFFF)) + (h2 >> np.uint64(16))).astype(np.int64)
+    s = (s - 131070).astype(np.float32)
+    scale = np.float32(std / IRWIN_HALL_SD)
+    return np.float32(mean) + s * scale          # two separately rounded fp32 ops (no FMA in numpy)
+
+
+def synth_bf16(shape: Tuple[int, ...], seed32: int, mean: float, std: float) -> torch.Tensor:
+    n = int(np.prod(shape))
+    out = torch.empty(n, dtype=torch.bfloat16)
+    step = 1 << 24                                   # bound temporary memory for the 131 M-element embeddings
+    for s in range(0, n, step):
+        m = min(step, n - s)
+        out[s:s + m] = torch.from_numpy(synth_f32(m, seed32, mean, std, s)).to(torch.bfloat16)   # RNE
+    return out.view(shape)
+
+
+def synth_state_dict(specs: Iterable, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """specs: objects with .name .shape .mean .std (bridgelang_amd.weights.tensor_specs) → HF-named bf16 CPU tensors."""
+    return {s.name: synth_bf16(tuple(s.shape), tensor_seed(s.name, seed), s.mean, s.std) for s in specs}
