@@ -1,0 +1,204 @@
+"""OpenVLA inference engine: static-shape op plans over the HIP kernels, replayed eagerly or as one HIP graph.
+
+The reference's `predict_action` = HF `generate(max_new_tokens=7)` over `PrismaticForConditionalGeneration.forward`
+(modeling_prismatic.py:506-536, 291-447): one multimodal prefill (vision towers → projector → splice → 32 Llama layers)
+and 6 cached decode steps, with a host round trip per token. Here the whole sequence — prefill, 6 decode steps, the
+greedy argmax of every step — is a fixed list of kernel launches on one stream with all intermediate buffers
+preallocated (activations for B=16 are < 1 GB of the 288 GB HBM), so it can be captured once and replayed with no host
+synchronisation until the 7 token ids are read back. Batched generation is an extension over the reference (batch 1
+only, modeling_prismatic.py:326,460-463); per-sample results equal independent batch-1 calls.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .ops import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_F32_BF16R, EPI_NONE, EPI_RES, EPI_SWIGLU, Op
+from .weights import TowerW, VLAWeights
+
+
+def rope_tables(head_dim: int, max_pos: int, theta: float, device) -> tuple:
+    """HF LlamaRotaryEmbedding on the host, exactly as the reference computes it (fp32 trig, cast to bf16), uploaded
+    once: [max_pos, head_dim/2] cos and sin tables."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    fr = torch.arange(max_pos, dtype=torch.float32)[:, None] * inv[None, :]
+    return fr.cos().to(torch.bfloat16).to(device), fr.sin().to(torch.bfloat16).to(device)
+
+
+class OpenVLAEngine:
+    def __init__(self, weights: VLAWeights, batch: int, prompt_len: int, n_new: int = 7):
+        self.w, self.dims = weights, weights.dims
+        d = self.dims
+        self.B, self.L, self.n_new = batch, prompt_len, n_new
+        self.S = prompt_len + d.n_patches
+        self.cache_len = (self.S + n_new + 63) // 64 * 64
+        if self.cache_len > d.max_pos:
+            raise ValueError("sequence exceeds max_position_embeddings")
+        dev = weights.embed.device
+        self.device = dev
+        B, S, D, I = batch, self.S, d.llm_dim, d.llm_inter
+        z = lambda *shape, dtype=torch.bfloat16: torch.zeros(*shape, dtype=dtype, device=dev)
+        # inputs / outputs (static addresses so a captured graph can be replayed)
+        self.pixel_values = z(B, 6, 224, 224)
+        self.input_ids = z(B, prompt_len, dtype=torch.int64)
+        self.gen_ids = z(n_new, B, dtype=torch.int64)
+        self.logits = z(n_new, B, d.vocab, dtype=torch.float32)
+        # vision buffers (sized for the larger tower, shared by both: they run back to back on one stream)
+        tmax = max(d.dino.tokens, d.siglip.tokens)
+        dmax = max(d.dino.dim, d.siglip.dim)
+        hmax = max(d.dino.mlp_pad, d.siglip.mlp_pad)
+        self.v_col = z(B * 256, (d.patch_k + 63) // 64 * 64)
+        self.v_x, self.v_h, self.v_ao = (z(B * tmax * dmax) for _ in range(3))
+        self.v_qkv = z(B * tmax * 3 * dmax)
+        self.v_mlp = z(B * tmax * hmax)
+        self.feats = z(B * 256, d.vision_dim)
+        self.p1, self.p2 = z(B * 256, 4 * d.vision_dim), z(B * 256, D)
+        # llm buffers
+        self.x = z(B, S, D)
+        self.h, self.ao = z(B * S, D), z(B * S, D)
+        self.qkv = z(B * S, 3 * D)
+        self.act = z(B * S, I)
+        self.k_cache = [z(B, d.llm_heads, self.cache_len, d.head_dim) for _ in range(d.llm_layers)]
+        self.v_cache = [z(B, d.llm_heads, self.cache_len, d.head_dim) for _ in range(d.llm_layers)]
+        self.xd, self.hd, self.aod = z(B, D), z(B, D), z(B, D)
+        self.qkvd, self.actd = z(B, 3 * D), z(B, I)
+        self.cos, self.sin = rope_tables(d.head_dim, d.max_pos, d.rope_theta, dev)
+
+        self.vision_ops = self._plan_tower(weights.dino, 0) + self._plan_tower(weights.siglip, d.dino.dim)
+        self.projector_ops = self._plan_projector()
+        self.prefill_ops = self._plan_prefill()
+        self.decode_ops = [self._plan_decode(t) for t in range(1, n_new)]
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+
+    # ---- plans ----------------------------------------------------------------------------------------------------
+    def _plan_tower(self, tw: TowerW, feat_col: int) -> List[Op]:
+        """timm VisionTransformer up to the tap: K1-K9 of SURVEY §2.4."""
+        t, B = tw.dims, self.B
+        T, Dm, Hp, hd = t.tokens, t.dim, t.mlp_pad, t.head_dim
+        M = B * T
+        x = self.v_x[:M * Dm].view(M, Dm)
+        h = self.v_h[:M * Dm].view(M, Dm)
+        ao = self.v_ao[:M * Dm].view(M, Dm)
+        qkv = self.v_qkv[:M * 3 * Dm].view(M, 3 * Dm)
+        mlp = self.v_mlp[:M * Hp].view(M, Hp)
+        plan = [ops.im2col_patch14(self.pixel_values, t.chan0, self.v_col, run=False)]
+        if tw.prefix is not None:
+            plan.append(ops.write_prefix_tokens(tw.prefix, x, B, T, run=False))
+        # patch-embed GEMM + bias + pos-embed, rows written behind the prefix tokens
+        plan.append(ops.gemm(self.v_col, tw.patch_w, x, EPI_BIAS_RES, bias=tw.patch_b, res=tw.pos, res_row_mod=256,
+                             out_map=(256, T, t.n_prefix), run=False))
+        st = (T * 3 * Dm, hd, 3 * Dm)
+        for i, b in enumerate(tw.blocks):
+            plan.append(ops.layernorm(x, b.norm1_w, b.norm1_b, h, self.dims.ln_eps, run=False))
+            plan.append(ops.gemm(h, b.qkv_w, qkv, EPI_BIAS, bias=b.qkv_b, run=False))
+            plan.append(ops.attention(qkv, qkv[:, Dm:], qkv[:, 2 * Dm:], ao, B=B, H=t.heads, Sq=T, Skv=T, head_dim=hd,
+                                      q_strides=st, k_strides=st, v_strides=st, o_strides=(T * Dm, hd, Dm),
+                                      causal=False, run=False))
+            plan.append(ops.gemm(ao, b.proj_w, x, EPI_BIAS_RES, bias=b.proj_b, scale=b.ls1, res=x, run=False))
+            plan.append(ops.layernorm(x, b.norm2_w, b.norm2_b, h, self.dims.ln_eps, run=False))
+            plan.append(ops.gemm(h, b.fc1_w, mlp, EPI_BIAS_GELU, bias=b.fc1_b, run=False))
+            if i + 1 < len(tw.blocks):
+                plan.append(ops.gemm(mlp, b.fc2_w, x, EPI_BIAS_RES, bias=b.fc2_b, scale=b.ls2, res=x, run=False))
+            else:   # tap: drop the prefix tokens and write this tower's channels of the fused feature map
+                plan.append(ops.gemm(mlp, b.fc2_w, self.feats[:, feat_col:feat_col + Dm], EPI_BIAS_RES, bias=b.fc2_b,
+                                     scale=b.ls2, res=x, out_map=(T, 256, -t.n_prefix), run=False))
+        return plan
+
+    def _plan_projector(self) -> List[Op]:
+        """PrismaticProjector (modeling_prismatic.py:151-156); fc3 writes straight into LLM embedding rows 1..256."""
+        w, B, S, D = self.w, self.B, self.S, self.dims.llm_dim
+        return [ops.gemm(self.feats, w.fc1_w, self.p1, EPI_BIAS_GELU, bias=w.fc1_b, run=False),
+                ops.gemm(self.p1, w.fc2_w, self.p2, EPI_BIAS_GELU, bias=w.fc2_b, run=False),
+                ops.gemm(self.p2, w.fc3_w, self.x.view(B * S, D), EPI_BIAS, bias=w.fc3_b, out_map=(256, S, 1), run=False)]
+
+    def _plan_prefill(self) -> List[Op]:
+        d, w, B, S = self.dims, self.w, self.B, self.S
+        D, H, hd = d.llm_dim, d.llm_heads, d.head_dim
+        x = self.x.view(B * S, D)
+        plan = [ops.embed_splice(self.input_ids, w.embed, self.x, d.n_patches, run=False)]
+        cs = (H * self.cache_len * hd, self.cache_len * hd, hd)
+        for l, lw in enumerate(w.layers):
+            plan.append(ops.rmsnorm(x, lw.ln1, self.h, d.rms_eps, run=False))
+            plan.append(ops.gemm(self.h, lw.qkv_w, self.qkv, EPI_NONE, run=False))
+            plan.append(ops.rope_kvcache(self.qkv, self.cos, self.sin, self.k_cache[l], self.v_cache[l], B=B, S=S, H=H,
+                                         head_dim=hd, pos0=0, run=False))
+            plan.append(ops.attention(self.qkv, self.k_cache[l], self.v_cache[l], self.ao, B=B, H=H, Sq=S, Skv=S,
+                                      head_dim=hd, q_strides=(S * 3 * D, hd, 3 * D), k_strides=cs, v_strides=cs,
+                                      o_strides=(S * D, hd, D), causal=True, run=False))
+            plan.append(ops.gemm(self.ao, lw.o_w, x, EPI_RES, res=x, run=False))
+            plan.append(ops.rmsnorm(x, lw.ln2, self.h, d.rms_eps, run=False))
+            plan.append(ops.gemm(self.h, lw.gu_w, self.act, EPI_SWIGLU, run=False))
+            plan.append(ops.gemm(self.act, lw.down_w, x, EPI_RES, res=x, run=False))
+        # final norm + lm_head on the last position only (the reference materialises all S rows)
+        last = self.x[:, S - 1, :]
+        plan.append(ops.rmsnorm(last, w.norm, self.hd, d.rms_eps, run=False))
+        plan.append(ops.gemm(self.hd, w.lm_head, self.logits[0], EPI_F32_BF16R, run=False))
+        plan.append(ops.argmax(self.logits[0], self.gen_ids[0], run=False))
+        return plan
+
+    def _plan_decode(self, t: int) -> List[Op]:
+        """Cached-generation step t (modeling_prismatic.py:325-341): token gen_ids[t-1] at position S+t-1."""
+        d, w, B = self.dims, self.w, self.B
+        D, H, hd = d.llm_dim, d.llm_heads, d.head_dim
+        pos = self.S + t - 1
+        cs = (H * self.cache_len * hd, self.cache_len * hd, hd)
+        plan = [ops.embed_splice(self.gen_ids[t - 1].view(B, 1), w.embed, self.xd.view(B, 1, D), 0, run=False)]
+        for l, lw in enumerate(w.layers):
+            plan.append(ops.rmsnorm(self.xd, lw.ln1, self.hd, d.rms_eps, run=False))
+            plan.append(ops.gemm(self.hd, lw.qkv_w, self.qkvd, EPI_NONE, run=False))
+            plan.append(ops.rope_kvcache(self.qkvd, self.cos, self.sin, self.k_cache[l], self.v_cache[l], B=B, S=1, H=H,
+                                         head_dim=hd, pos0=pos, run=False))
+            plan.append(ops.attention_decode(self.qkvd, self.k_cache[l], self.v_cache[l], self.aod, B=B, H=H,
+                                             Skv=pos + 1, head_dim=hd, q_strides=(3 * D, hd, 3 * D), k_strides=cs,
+                                             v_strides=cs, o_strides=(D, hd, D), run=False))
+            plan.append(ops.gemm(self.aod, lw.o_w, self.xd, EPI_RES, res=self.xd, run=False))
+            plan.append(ops.rmsnorm(self.xd, lw.ln2, self.hd, d.rms_eps, run=False))
+            plan.append(ops.gemm(self.hd, lw.gu_w, self.actd, EPI_SWIGLU, run=False))
+            plan.append(ops.gemm(self.actd, lw.down_w, self.xd, EPI_RES, res=self.xd, run=False))
+        plan.append(ops.rmsnorm(self.xd, w.norm, self.hd, d.rms_eps, run=False))
+        plan.append(ops.gemm(self.hd, w.lm_head, self.logits[t], EPI_F32_BF16R, run=False))
+        plan.append(ops.argmax(self.logits[t], self.gen_ids[t], run=False))
+        return plan
+
+    # ---- execution ------------------------------------------------------------------------------------------------
+    def all_ops(self) -> List[Op]:
+        out = self.vision_ops + self.projector_ops + self.prefill_ops
+        for step in self.decode_ops:
+            out = out + step
+        return out
+
+    def run_eager(self) -> None:
+        ops.run_all(self.all_ops())
+
+    def capture(self) -> None:
+        """Capture the whole action-sequence computation into one HIP graph (after one eager warm-up launch)."""
+        self.run_eager()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            ops.run_all(self.all_ops())
+        self._graph = g
+
+    def replay(self) -> None:
+        if self._graph is None:
+            self.run_eager()
+        else:
+            self._graph.replay()
+
+    def set_inputs(self, input_ids: torch.Tensor, pixel_values: torch.Tensor) -> None:
+        if tuple(input_ids.shape) != (self.B, self.L):
+            raise ValueError(f"engine built for input_ids {(self.B, self.L)}, got {tuple(input_ids.shape)}")
+        if tuple(pixel_values.shape) != (self.B, 6, 224, 224):
+            raise ValueError(f"pixel_values must be [{self.B}, 6, 224, 224]")
+        self.input_ids.copy_(input_ids)
+        self.pixel_values.copy_(pixel_values.to(torch.bfloat16))
+
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor, pixel_values: torch.Tensor) -> torch.Tensor:
+        """Greedy n_new tokens for every sequence. Returns int64 [B, n_new] (device tensor; no host sync inside)."""
+        self.set_inputs(input_ids, pixel_values)
+        self.replay()
+        return self.gen_ids.t()

@@ -1,0 +1,282 @@
+"""GPU parity tests, one per C-ABI entry point: HIP kernel vs the CPU oracle (oracle/restate.py, oracle/synth.py) on
+the same seeded bf16 inputs. Integer/index results are bit-exact; bf16 results must agree to within one bf16 rounding
+(the only legitimate difference is fp32 accumulation order), which the tests express as rtol = 2^-6 on ≥ 99 % exactly
+equal elements.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rand_bf16
+from oracle import restate as R
+from oracle import synth as S
+
+pytestmark = pytest.mark.gpu
+
+P = R.Prec(True)
+
+
+def dv(x, dev):
+    return x.to(torch.bfloat16).to(dev)
+
+
+def close_bf16(got, ref, what, rtol=2 ** -6, atol_scale=2 ** -8, min_exact=0.98):
+    got = got.float().cpu()
+    ref = ref.float()
+    assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs()
+    bound = rtol * ref.abs() + atol_scale * scale
+    exact = (got == ref).float().mean().item()
+    assert (err <= bound).all(), (f"{what}: max err {err.max().item():.4g} (scale {scale:.4g}), "
+                                  f"{(err > bound).sum().item()} elements out of tolerance, exact {exact:.4f}")
+    assert exact >= min_exact, f"{what}: only {exact:.4f} of elements bit-equal to the oracle"
+
+
+# ---- synthetic generator: bit exact -------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,mean,std", [((1000,), 0.0, 0.02), ((37, 588), 1.0, 0.02), ((4096,), 0.1, 0.02)])
+def test_fill_synth_bit_exact(dev, shape, mean, std):
+    from bridgelang_amd import ops
+    seed = S.tensor_seed("some.tensor.name", 3)
+    n = int(np.prod(shape))
+    got = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    ops.fill_synth(got, seed, mean, std / S.IRWIN_HALL_SD)
+    ref = S.synth_bf16(shape, seed, mean, std).view(-1)
+    assert torch.equal(got.cpu().view(torch.int16), ref.view(torch.int16))
+
+
+def test_fill_synth_padded_and_interleaved(dev):
+    from bridgelang_amd import ops
+    rows, cols, ld = 33, 588, 640
+    seed = 1234
+    got = torch.zeros(rows, ld, dtype=torch.bfloat16, device=dev)
+    ops.fill_synth(got.view(-1), seed, 0.0, 0.02 / S.IRWIN_HALL_SD, rows=rows, cols=cols, ld=ld)
+    ref = S.synth_bf16((rows, cols), seed, 0.0, 0.02)
+    assert torch.equal(got.cpu()[:, :cols], ref)
+    assert (got.cpu()[:, cols:] == 0).all()
+    # interleave two logical matrices row-wise (the gate/up packing)
+    I, D = 48, 64
+    gu = torch.zeros(2 * I, D, dtype=torch.bfloat16, device=dev)
+    ops.fill_synth(gu.view(-1), 11, 0.0, 0.02 / S.IRWIN_HALL_SD, rows=I, cols=D, ld=2 * D)
+    ops.fill_synth(gu.view(-1)[D:], 12, 0.0, 0.02 / S.IRWIN_HALL_SD, rows=I, cols=D, ld=2 * D)
+    g, u = S.synth_bf16((I, D), 11, 0.0, 0.02), S.synth_bf16((I, D), 12, 0.0, 0.02)
+    assert torch.equal(gu.cpu()[0::2], g) and torch.equal(gu.cpu()[1::2], u)
+
+
+# ---- tiled GEMM -----------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [(300, 192, 128), (128, 128, 64), (261 * 2, 1152, 576), (77, 4304 // 16 * 16, 256), (1, 64, 64)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_none_bias_gelu(dev, M, N, K):
+    from bridgelang_amd import ops
+    a, w, b = rand_bf16((M, K), 1), rand_bf16((N, K), 2, 0.05), rand_bf16((N,), 3, 0.1)
+    A, W, Bv = dv(a, dev), dv(w, dev), dv(b, dev)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(A, W, out, ops.EPI_NONE, skinny=False)
+    close_bf16(out, R.linear(P, a, w), "EPI_NONE")
+    ops.gemm(A, W, out, ops.EPI_BIAS, bias=Bv, skinny=False)
+    close_bf16(out, R.linear(P, a, w, b), "EPI_BIAS")
+    ops.gemm(A, W, out, ops.EPI_BIAS_GELU, bias=Bv, skinny=False)
+    close_bf16(out, R.gelu(P, R.linear(P, a, w, b)), "EPI_BIAS_GELU")
+    outf = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ops.gemm(A, W, outf, ops.EPI_F32, skinny=False)
+    ref = a @ w.t()
+    assert torch.allclose(outf.cpu(), ref, rtol=1e-4, atol=1e-4 * ref.abs().max().item())
+    ops.gemm(A, W, outf, ops.EPI_F32_BF16R, skinny=False)
+    close_bf16(outf, R.linear(P, a, w), "EPI_F32_BF16R")
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 192, 128), (522, 256, 1088)])
+def test_gemm_residual_layerscale_swiglu(dev, M, N, K):
+    from bridgelang_amd import ops
+    a, w, b = rand_bf16((M, K), 1), rand_bf16((N, K), 2, 0.05), rand_bf16((N,), 3, 0.1)
+    r, ls = rand_bf16((M, N), 4), rand_bf16((N,), 5, 0.3)
+    A, W, Bv, Rr, Ls = (dv(t, dev) for t in (a, w, b, r, ls))
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(A, W, out, ops.EPI_RES, res=Rr, skinny=False)
+    close_bf16(out, P.rb(r + R.linear(P, a, w)), "EPI_RES")
+    ops.gemm(A, W, out, ops.EPI_BIAS_RES, bias=Bv, res=Rr, skinny=False)
+    close_bf16(out, P.rb(r + R.linear(P, a, w, b)), "EPI_BIAS_RES")
+    ops.gemm(A, W, out, ops.EPI_BIAS_RES, bias=Bv, scale=Ls, res=Rr, skinny=False)
+    close_bf16(out, P.rb(r + P.rb(R.linear(P, a, w, b) * ls)), "EPI_BIAS_RES+LayerScale")
+    # in-place residual (out aliases res), as the engine uses it
+    x = Rr.clone()
+    ops.gemm(A, W, x, ops.EPI_RES, res=x, skinny=False)
+    close_bf16(x, P.rb(r + R.linear(P, a, w)), "EPI_RES in place")
+    # SwiGLU with interleaved gate/up rows
+    I = N // 2
+    gate, up = w[:I], w[I:]
+    gu = torch.stack([gate, up], 1).reshape(N, K)
+    out2 = torch.empty(M, I, dtype=torch.bfloat16, device=dev)
+    ops.gemm(A, dv(gu, dev), out2, ops.EPI_SWIGLU, skinny=False)
+    g, u = R.linear(P, a, gate), R.linear(P, a, up)
+    close_bf16(out2, P.rb(P.rb(torch.nn.functional.silu(g)) * u), "EPI_SWIGLU")
+
+
+def test_gemm_row_remap_and_table_residual(dev):
+    """patch-embed style: + pos[m % 256], rows written behind 5 prefix tokens; and the tap: drop 5 prefix rows."""
+    from bridgelang_amd import ops
+    B, D, K = 2, 128, 640
+    a, w, b, pos = rand_bf16((B * 256, K), 1), rand_bf16((D, K), 2, 0.05), rand_bf16((D,), 3, 0.1), rand_bf16((256, D), 4)
+    out = torch.full((B * 261, D), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.gemm(dv(a, dev), dv(w, dev), out, ops.EPI_BIAS_RES, bias=dv(b, dev), res=dv(pos, dev), res_row_mod=256,
+             out_map=(256, 261, 5))
+    ref = P.rb(R.linear(P, a, w, b).view(B, 256, D) + pos)
+    got = out.cpu().float().view(B, 261, D)
+    close_bf16(got[:, 5:], ref, "patch-embed remap")
+    assert (got[:, :5] == 7.0).all(), "prefix rows must not be touched"
+    # tap: input rows [B*261], output only the 256 patch rows per image, into a wider concat buffer
+    x = rand_bf16((B * 261, K), 9)
+    cat = torch.zeros(B * 256, D + 64, dtype=torch.bfloat16, device=dev)
+    ops.gemm(dv(x, dev), dv(w, dev), cat[:, 64:], ops.EPI_BIAS, bias=dv(b, dev), out_map=(261, 256, -5))
+    ref2 = R.linear(P, x, w, b).view(B, 261, D)[:, 5:].reshape(B * 256, D)
+    close_bf16(cat[:, 64:], ref2, "tap remap")
+    assert (cat[:, :64] == 0).all()
+
+
+# ---- skinny GEMM ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(16, 512, 512), (1, 1536 * 2, 512), (16, 512, 1536), (7, 4096, 4096), (16, 256, 11008)])
+def test_gemm_skinny(dev, M, N, K):
+    from bridgelang_amd import ops
+    a, w, r = rand_bf16((M, K), 1), rand_bf16((N, K), 2, 0.05), rand_bf16((M, N), 4)
+    A, W, Rr = dv(a, dev), dv(w, dev), dv(r, dev)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(A, W, out, ops.EPI_NONE, skinny=True)
+    close_bf16(out, R.linear(P, a, w), "skinny NONE")
+    ops.gemm(A, W, out, ops.EPI_RES, res=Rr, skinny=True)
+    close_bf16(out, P.rb(r + R.linear(P, a, w)), "skinny RES")
+    I = N // 2
+    gu = torch.stack([w[:I], w[I:]], 1).reshape(N, K)
+    out2 = torch.empty(M, I, dtype=torch.bfloat16, device=dev)
+    ops.gemm(A, dv(gu, dev), out2, ops.EPI_SWIGLU, skinny=True)
+    g, u = R.linear(P, a, w[:I]), R.linear(P, a, w[I:])
+    close_bf16(out2, P.rb(P.rb(torch.nn.functional.silu(g)) * u), "skinny SWIGLU")
+    outf = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ops.gemm(A, W, outf, ops.EPI_F32_BF16R, skinny=True)
+    close_bf16(outf, R.linear(P, a, w), "skinny F32_BF16R")
+
+
+# ---- norms ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,dim", [(9, 1024), (261, 1152), (5, 576), (33, 4096), (3, 5120), (2, 256)])
+def test_norms(dev, rows, dim):
+    from bridgelang_amd import ops
+    x, w, b = rand_bf16((rows, dim), 1, 3.0), rand_bf16((dim,), 2, 0.02) + 1, rand_bf16((dim,), 3, 0.02)
+    w = P.rb(w)
+    X, W, Bv = dv(x, dev), dv(w, dev), dv(b, dev)
+    y = torch.empty_like(X)
+    ops.layernorm(X, W, Bv, y, 1e-6)
+    close_bf16(y, R.layernorm(P, x, w, b, 1e-6), "layernorm")
+    ops.rmsnorm(X, W, y, 1e-6)
+    close_bf16(y, R.rmsnorm(P, x, w, 1e-6), "rmsnorm")
+
+
+# ---- attention ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("hd,H,Sq,causal", [(64, 4, 261, False), (72, 8, 256, False), (128, 4, 288, True),
+                                            (128, 2, 70, True), (64, 2, 17, False), (128, 2, 296, True)])
+def test_attention_prefill(dev, hd, H, Sq, causal):
+    from bridgelang_amd import ops
+    B, D = 2, H * hd
+    qkv = rand_bf16((B * Sq, 3 * D), hd + Sq)
+    Q = dv(qkv, dev)
+    o = torch.zeros(B * Sq, D, dtype=torch.bfloat16, device=dev)
+    st = (Sq * 3 * D, hd, 3 * D)
+    ops.attention(Q, Q[:, D:], Q[:, 2 * D:], o, B=B, H=H, Sq=Sq, Skv=Sq, head_dim=hd, q_strides=st, k_strides=st,
+                  v_strides=st, o_strides=(Sq * D, hd, D), causal=causal)
+    t = qkv.view(B, Sq, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = R.attention(P, t[0], t[1], t[2], hd ** -0.5, causal).permute(0, 2, 1, 3).reshape(B * Sq, D)
+    close_bf16(o, ref, f"attention hd={hd}", rtol=2 ** -5, atol_scale=2 ** -7, min_exact=0.55)
+
+
+def test_attention_key_mask(dev):
+    from bridgelang_amd import ops
+    B, H, hd, S = 3, 2, 128, 100
+    D = H * hd
+    qkv = rand_bf16((B * S, 3 * D), 5)
+    lens = [100, 63, 17]
+    mask = torch.zeros(B, S, dtype=torch.uint8)
+    for i, n in enumerate(lens):
+        mask[i, :n] = 1
+    Q = dv(qkv, dev)
+    o = torch.zeros(B * S, D, dtype=torch.bfloat16, device=dev)
+    st = (S * 3 * D, hd, 3 * D)
+    ops.attention(Q, Q[:, D:], Q[:, 2 * D:], o, B=B, H=H, Sq=S, Skv=S, head_dim=hd, q_strides=st, k_strides=st,
+                  v_strides=st, o_strides=(S * D, hd, D), causal=True, key_mask=mask.to(dev))
+    t = qkv.view(B, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = R.attention(P, t[0], t[1], t[2], hd ** -0.5, True, key_mask=mask).permute(0, 2, 1, 3)
+    got = o.cpu().float().view(B, S, H, hd)
+    for i, n in enumerate(lens):     # rows of padded queries are unspecified (ignored by the loss)
+        close_bf16(got[i, :n], ref[i, :n], f"masked attention b={i}", rtol=2 ** -5, atol_scale=2 ** -7, min_exact=0.55)
+
+
+@pytest.mark.parametrize("Skv", [1, 67, 289, 294])
+def test_attention_decode(dev, Skv):
+    from bridgelang_amd import ops
+    B, H, hd, cache_len = 3, 4, 128, 320
+    D = H * hd
+    q = rand_bf16((B, D), 1)
+    kc, vc = rand_bf16((B, H, cache_len, hd), 2), rand_bf16((B, H, cache_len, hd), 3)
+    o = torch.zeros(B, D, dtype=torch.bfloat16, device=dev)
+    cs = (H * cache_len * hd, cache_len * hd, hd)
+    ops.attention_decode(dv(q, dev), dv(kc, dev), dv(vc, dev), o, B=B, H=H, Skv=Skv, head_dim=hd,
+                         q_strides=(D, hd, D), k_strides=cs, v_strides=cs, o_strides=(D, hd, D))
+    ref = R.attention(P, q.view(B, H, 1, hd), kc[:, :, :Skv], vc[:, :, :Skv], hd ** -0.5, False).reshape(B, D)
+    close_bf16(o, ref, "decode attention", rtol=2 ** -5, atol_scale=2 ** -7, min_exact=0.55)
+
+
+# ---- Llama glue -----------------------------------------------------------------------------------------------------
+def test_rope_kvcache(dev):
+    from bridgelang_amd import ops
+    B, S, H, hd, cache_len, pos0 = 2, 37, 4, 128, 64, 3
+    D = H * hd
+    qkv = rand_bf16((B * S, 3 * D), 8)
+    cos, sin = R.rope_tables(hd, 256, 10000.0)
+    Q = dv(qkv, dev)
+    kc = torch.zeros(B, H, cache_len, hd, dtype=torch.bfloat16, device=dev)
+    vc = torch.zeros_like(kc)
+    ops.rope_kvcache(Q, dv(cos, dev), dv(sin, dev), kc, vc, B=B, S=S, H=H, head_dim=hd, pos0=pos0)
+    t = qkv.view(B, S, 3, H, hd).permute(2, 0, 3, 1, 4)       # [3, B, H, S, hd]
+    q_ref, k_ref = R.apply_rope(P, t[0], cos, sin, pos0), R.apply_rope(P, t[1], cos, sin, pos0)
+    got = Q.cpu().float().view(B, S, 3, H, hd)
+    assert torch.equal(got[:, :, 0].permute(0, 2, 1, 3), q_ref), "rotated q must be bit-exact"
+    assert torch.equal(got[:, :, 2], qkv.view(B, S, 3, H, hd)[:, :, 2]), "v must be untouched"
+    assert torch.equal(kc.cpu().float()[:, :, pos0:pos0 + S], k_ref), "cached k must be bit-exact"
+    assert torch.equal(vc.cpu().float()[:, :, pos0:pos0 + S], t[2]), "cached v must be bit-exact"
+    assert (kc.cpu()[:, :, :pos0] == 0).all() and (kc.cpu()[:, :, pos0 + S:] == 0).all()
+
+
+def test_embed_splice_argmax_im2col_prefix(dev):
+    from bridgelang_amd import ops
+    B, L, dim, V, npatch = 3, 9, 64, 100, 16
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, V, (B, L), generator=g)
+    table = rand_bf16((V, dim), 1)
+    dst = torch.full((B, L + npatch, dim), 5.0, dtype=torch.bfloat16, device=dev)
+    ops.embed_splice(ids.to(dev), dv(table, dev), dst, npatch)
+    got = dst.cpu().float()
+    assert torch.equal(got[:, 0], table[ids[:, 0]]) and torch.equal(got[:, 1 + npatch:], table[ids[:, 1:]])
+    assert (got[:, 1:1 + npatch] == 5.0).all()
+    # argmax with ties → first index
+    lg = torch.randn(5, 32064, generator=g)
+    lg[1, 100] = lg[1, 31000] = 50.0
+    lg[2, 32063] = 60.0
+    lg[3, 0] = 70.0
+    out = torch.zeros(5, dtype=torch.int64, device=dev)
+    ops.argmax(lg.to(dev), out)
+    assert torch.equal(out.cpu(), lg.argmax(-1)) and out[1].item() == 100
+    # im2col
+    pv = rand_bf16((2, 6, 224, 224), 3)
+    for chan0 in (0, 3):
+        col = torch.full((2 * 256, 640), 9.0, dtype=torch.bfloat16, device=dev)
+        ops.im2col_patch14(dv(pv, dev), chan0, col)
+        ref = R.im2col_patch14(pv[:, chan0:chan0 + 3].contiguous()).reshape(2 * 256, 588)
+        assert torch.equal(col.cpu().float()[:, :588], ref) and (col.cpu()[:, 588:] == 0).all()
+    # prefix tokens
+    x = torch.zeros(B * 21, dim, dtype=torch.bfloat16, device=dev)
+    pre = rand_bf16((5, dim), 4)
+    ops.write_prefix_tokens(dv(pre, dev), x, B, 21)
+    got = x.cpu().float().view(B, 21, dim)
+    assert torch.equal(got[:, :5], pre.expand(B, 5, dim)) and (got[:, 5:] == 0).all()
