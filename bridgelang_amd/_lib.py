@@ -67,6 +67,7 @@ SIGNATURES = {
     "bl_rope_kvcache_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "bl_embed_splice_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "bl_argmax_f32": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "bl_cross_entropy_f32": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
     "bl_im2col_patch14_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _vp]),
     "bl_write_prefix_tokens_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp]),
 }

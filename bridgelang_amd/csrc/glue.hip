@@ -153,6 +153,62 @@ __global__ void write_prefix_kernel(const uint16_t* prefix, int n_prefix, int di
   }
 }
 
+// ---- shifted cross-entropy over fp32 logits (HF CausalLM loss, ignore_index = -100) ----
+// One workgroup per row: loss[row] = logsumexp(logits[row]) - logits[row][target]; rows whose target is ignored get 0.
+__global__ __launch_bounds__(256) void cross_entropy_rows_kernel(const float* logits, long ld, int n,
+                                                                 const int64_t* targets, long ignore_index,
+                                                                 float* row_loss) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const long tgt = targets[row];
+  if (tgt == ignore_index) {          // uniform per workgroup
+    if (threadIdx.x == 0) row_loss[row] = 0.f;
+    return;
+  }
+  const float* lr = logits + (long)row * ld;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x * 4; i < n; i += 1024) {
+    const f32x4_t q = *(const f32x4_t*)(lr + i);
+    mx = fmaxf(fmaxf(mx, fmaxf(q[0], q[1])), fmaxf(q[2], q[3]));
+  }
+  mx = wave_max(mx);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int i = threadIdx.x * 4; i < n; i += 1024) {
+    const f32x4_t q = *(const f32x4_t*)(lr + i);
+    s += expf(q[0] - mx) + expf(q[1] - mx) + expf(q[2] - mx) + expf(q[3] - mx);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) row_loss[row] = logf(red[0] + red[1] + red[2] + red[3]) + mx - lr[tgt];
+}
+
+// mean of row_loss over rows whose target is not ignored (single workgroup, fixed summation order → deterministic)
+__global__ __launch_bounds__(256) void masked_mean_kernel(const float* row_loss, const int64_t* targets, long ignore_index,
+                                                          int rows, float* out) {
+  __shared__ float rs[4];
+  __shared__ int rc[4];
+  float s = 0.f;
+  int c = 0;
+  for (int i = threadIdx.x; i < rows; i += 256)
+    if (targets[i] != ignore_index) { s += row_loss[i]; ++c; }
+  s = wave_sum(s);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rc[threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int cnt = rc[0] + rc[1] + rc[2] + rc[3];
+    out[0] = cnt > 0 ? (rs[0] + rs[1] + rs[2] + rs[3]) / (float)cnt : 0.f;
+    out[1] = (float)cnt;
+  }
+}
+
 inline int grid_for(long total, int block) {
   long g = (total + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));   // cap at 256 CUs × 8 and grid-stride the rest
@@ -233,6 +289,19 @@ extern "C" int bl_write_prefix_tokens_bf16(const bl_bf16* prefix, int32_t n_pref
   const long total = (long)B * n_prefix * (dim / 8);
   hipLaunchKernelGGL(write_prefix_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, prefix,
                      n_prefix, dim, x, B, T);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_cross_entropy_f32(const float* logits, int64_t ld, int32_t rows, int32_t n, const int64_t* targets,
+                                    int64_t ignore_index, float* row_loss, float* mean_and_count, void* stream) {
+  if (!logits || !targets || !row_loss || !mean_and_count) return BL_E_ARG;
+  if (rows <= 0 || n <= 0 || (n % 4) || (ld % 4)) return BL_E_SHAPE;
+  if (!bl_aligned16(logits)) return BL_E_ALIGN;
+  hipLaunchKernelGGL(cross_entropy_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, n,
+                     targets, (long)ignore_index, row_loss);
+  hipLaunchKernelGGL(masked_mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_loss, targets,
+                     (long)ignore_index, rows, mean_and_count);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

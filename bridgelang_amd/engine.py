@@ -29,9 +29,16 @@ def rope_tables(head_dim: int, max_pos: int, theta: float, device) -> tuple:
 
 
 class OpenVLAEngine:
-    def __init__(self, weights: VLAWeights, batch: int, prompt_len: int, n_new: int = 7):
+    def __init__(self, weights: VLAWeights, batch: int, prompt_len: int, n_new: int = 7, all_rows: bool = False,
+                 use_mask: bool = False):
+        """all_rows=True builds the training/eval-style forward instead of generation: logits for every position
+        (`logits_all` [B*S, vocab] fp32) and no decode steps. use_mask=True threads a [B, S] uint8 key-padding mask
+        (`key_mask`, 1 = attend) through the Llama attention (modeling_prismatic.py:387-390)."""
         self.w, self.dims = weights, weights.dims
         d = self.dims
+        if all_rows:
+            n_new = 1
+        self.all_rows, self.use_mask = all_rows, use_mask
         self.B, self.L, self.n_new = batch, prompt_len, n_new
         self.S = prompt_len + d.n_patches
         self.cache_len = (self.S + n_new + 63) // 64 * 64
@@ -66,6 +73,8 @@ class OpenVLAEngine:
         self.xd, self.hd, self.aod = z(B, D), z(B, D), z(B, D)
         self.qkvd, self.actd = z(B, 3 * D), z(B, I)
         self.cos, self.sin = rope_tables(d.head_dim, d.max_pos, d.rope_theta, dev)
+        self.key_mask = torch.ones(B, S, dtype=torch.uint8, device=dev) if use_mask else None
+        self.logits_all = z(B * S, d.vocab, dtype=torch.float32) if all_rows else None
 
         self.vision_ops = self._plan_tower(weights.dino, 0) + self._plan_tower(weights.siglip, d.dino.dim)
         self.projector_ops = self._plan_projector()
@@ -89,7 +98,7 @@ class OpenVLAEngine:
             plan.append(ops.write_prefix_tokens(tw.prefix, x, B, T, run=False))
         # patch-embed GEMM + bias + pos-embed, rows written behind the prefix tokens
         plan.append(ops.gemm(self.v_col, tw.patch_w, x, EPI_BIAS_RES, bias=tw.patch_b, res=tw.pos, res_row_mod=256,
-                             out_map=(256, T, t.n_prefix), run=False))
+                             out_map=(256, T, t.n_prefix), algo_nk=(Dm, self.dims.patch_k), run=False))
         st = (T * 3 * Dm, hd, 3 * Dm)
         for i, b in enumerate(tw.blocks):
             plan.append(ops.layernorm(x, b.norm1_w, b.norm1_b, h, self.dims.ln_eps, run=False))
@@ -99,12 +108,13 @@ class OpenVLAEngine:
                                       causal=False, run=False))
             plan.append(ops.gemm(ao, b.proj_w, x, EPI_BIAS_RES, bias=b.proj_b, scale=b.ls1, res=x, run=False))
             plan.append(ops.layernorm(x, b.norm2_w, b.norm2_b, h, self.dims.ln_eps, run=False))
-            plan.append(ops.gemm(h, b.fc1_w, mlp, EPI_BIAS_GELU, bias=b.fc1_b, run=False))
+            plan.append(ops.gemm(h, b.fc1_w, mlp, EPI_BIAS_GELU, bias=b.fc1_b, algo_nk=(t.mlp, Dm), run=False))
             if i + 1 < len(tw.blocks):
-                plan.append(ops.gemm(mlp, b.fc2_w, x, EPI_BIAS_RES, bias=b.fc2_b, scale=b.ls2, res=x, run=False))
+                plan.append(ops.gemm(mlp, b.fc2_w, x, EPI_BIAS_RES, bias=b.fc2_b, scale=b.ls2, res=x, algo_nk=(Dm, t.mlp),
+                                     run=False))
             else:   # tap: drop the prefix tokens and write this tower's channels of the fused feature map
                 plan.append(ops.gemm(mlp, b.fc2_w, self.feats[:, feat_col:feat_col + Dm], EPI_BIAS_RES, bias=b.fc2_b,
-                                     scale=b.ls2, res=x, out_map=(T, 256, -t.n_prefix), run=False))
+                                     scale=b.ls2, res=x, out_map=(T, 256, -t.n_prefix), algo_nk=(Dm, t.mlp), run=False))
         return plan
 
     def _plan_projector(self) -> List[Op]:
@@ -127,11 +137,15 @@ class OpenVLAEngine:
                                          head_dim=hd, pos0=0, run=False))
             plan.append(ops.attention(self.qkv, self.k_cache[l], self.v_cache[l], self.ao, B=B, H=H, Sq=S, Skv=S,
                                       head_dim=hd, q_strides=(S * 3 * D, hd, 3 * D), k_strides=cs, v_strides=cs,
-                                      o_strides=(S * D, hd, D), causal=True, run=False))
+                                      o_strides=(S * D, hd, D), causal=True, key_mask=self.key_mask, run=False))
             plan.append(ops.gemm(self.ao, lw.o_w, x, EPI_RES, res=x, run=False))
             plan.append(ops.rmsnorm(x, lw.ln2, self.h, d.rms_eps, run=False))
             plan.append(ops.gemm(self.h, lw.gu_w, self.act, EPI_SWIGLU, run=False))
             plan.append(ops.gemm(self.act, lw.down_w, x, EPI_RES, res=x, run=False))
+        if self.all_rows:   # HF semantics: logits for every position (what forward()/training consume)
+            plan.append(ops.rmsnorm(x, w.norm, self.h, d.rms_eps, run=False))
+            plan.append(ops.gemm(self.h, w.lm_head, self.logits_all, EPI_F32_BF16R, run=False))
+            return plan
         # final norm + lm_head on the last position only (the reference materialises all S rows)
         last = self.x[:, S - 1, :]
         plan.append(ops.rmsnorm(last, w.norm, self.hd, d.rms_eps, run=False))

@@ -1,0 +1,213 @@
+"""`OpenVLAForActionPrediction` on MI355X: the reference's HF-style model surface over the HIP engine.
+
+Drop-in for prismatic/extern/hf/modeling_prismatic.py: same class names, `forward()` keyword list and output dataclass
+(:291-304, :162-173), `predict_action(input_ids, unnorm_key, **kwargs)` (:506-536), `get_action_dim` /
+`get_action_stats` / `_check_unnorm_key` (:538-562) and the attributes callers read (`norm_stats`, `bins`,
+`bin_centers`, `vocab_size`, `config.image_sizes`, `vision_backbone.featurizer.patch_embed.num_patches` —
+finetune.py:219,270). What sits behind it is not timm/transformers/flash-attn but bridgelang_amd.engine (hand-written
+gfx950 kernels); there is no eager/PyTorch fallback, so constructing the model without a GPU + built library raises.
+
+Differences from the reference, all deliberate:
+  * batched `predict_action` is supported (returns [B, 7]); batch 1 returns the reference's 1-D array.
+  * the greedy loop runs on-device (no per-token host sync); `do_sample=True` is rejected.
+  * when 29871 is appended to the prompt the attention mask is extended with it (reference quirk C.1).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from ...engine import OpenVLAEngine
+from ...weights import TowerDims, VLADims, VLAWeights, allocate
+from .configuration_prismatic import OpenVLAConfig, PrismaticConfig
+
+IGNORE_INDEX = -100
+
+# timm id → tower geometry (timm 0.9.10 model definitions)
+_TIMM_GEOMETRY = {
+    "vit_large_patch14_reg4_dinov2.lvd142m": dict(dim=1024, depth=24, heads=16, mlp=4096, n_prefix=5, layerscale=True),
+    "vit_so400m_patch14_siglip_224": dict(dim=1152, depth=27, heads=16, mlp=4304, n_prefix=0, layerscale=False),
+}
+
+
+def dims_from_config(config: PrismaticConfig) -> VLADims:
+    if not config.use_fused_vision_backbone or len(config.timm_model_ids) != 2:
+        raise NotImplementedError("only the fused DINOv2+SigLIP backbone is on the MI355X path")
+    a, b = (_TIMM_GEOMETRY[i] for i in config.timm_model_ids)
+    tc = config.text_config
+    if tc.num_key_value_heads not in (None, tc.num_attention_heads):
+        raise NotImplementedError("grouped-query attention is not on the Llama-2 path")
+    return VLADims(dino=TowerDims("vision_backbone.featurizer", chan0=0, **a),
+                   siglip=TowerDims("vision_backbone.fused_featurizer", chan0=3, **b),
+                   llm_dim=tc.hidden_size, llm_layers=tc.num_hidden_layers, llm_heads=tc.num_attention_heads,
+                   llm_inter=tc.intermediate_size, vocab=tc.vocab_size, rms_eps=tc.rms_norm_eps,
+                   rope_theta=float(getattr(tc, "rope_theta", None) or 10000.0),
+                   max_pos=min(tc.max_position_embeddings, config.llm_max_length), name=config.llm_backbone_id)
+
+
+@dataclass
+class PrismaticCausalLMOutputWithPast:
+    """Field-for-field the reference's output class (modeling_prismatic.py:162-173)."""
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_key_values: Optional[Any] = None
+    hidden_states: Optional[Tuple[torch.Tensor, ...]] = None
+    attentions: Optional[Tuple[torch.Tensor]] = None
+    projector_features: Optional[torch.Tensor] = None
+
+    def to_tuple(self) -> tuple:
+        return tuple(v for v in (self.loss, self.logits, self.past_key_values, self.hidden_states, self.attentions,
+                                 self.projector_features) if v is not None)
+
+
+class PrismaticForConditionalGeneration:
+    config_class = PrismaticConfig
+
+    def __init__(self, config: PrismaticConfig, device: Union[str, torch.device] = "cuda:0",
+                 dims: Optional[VLADims] = None) -> None:
+        if config.use_fused_vision_backbone is None:
+            raise ValueError("Missing config field `use_fused_vision_backbone`")
+        self.config = config
+        self.device = torch.device(device)
+        self.dims = dims if dims is not None else dims_from_config(config)
+        self.weights: VLAWeights = allocate(self.dims, self.device)
+        self.vocab_size = self.dims.vocab
+        self.pad_token_id = config.pad_token_id
+        self.training = False
+        self._engines: Dict[Tuple[int, int], OpenVLAEngine] = {}
+        # attribute path read by finetune.py:270
+        self.vision_backbone = SimpleNamespace(
+            featurizer=SimpleNamespace(patch_embed=SimpleNamespace(num_patches=self.dims.n_patches)),
+            embed_dim=self.dims.vision_dim)
+
+    # ---- weights ----
+    def init_synthetic(self, seed: int = 0) -> "PrismaticForConditionalGeneration":
+        self.weights.fill_synthetic(seed)
+        return self
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        self.weights.load_state_dict(state_dict, strict=strict)
+        return self
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return self.weights.state_dict()
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def to(self, *args, **kwargs):   # weights live where they were allocated; kept for call-site compatibility
+        return self
+
+    def engine(self, batch: int, prompt_len: int) -> OpenVLAEngine:
+        key = (batch, prompt_len)
+        if key not in self._engines:
+            self._engines[key] = OpenVLAEngine(self.weights, batch, prompt_len)
+        return self._engines[key]
+
+    # ---- forward (multimodal prefill; logits for all positions) ----
+    @torch.no_grad()
+    def forward(self, input_ids: Optional[torch.LongTensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                pixel_values: Optional[torch.FloatTensor] = None, labels: Optional[torch.LongTensor] = None,
+                inputs_embeds: Optional[torch.FloatTensor] = None, past_key_values: Optional[Any] = None,
+                use_cache: Optional[bool] = None, output_attentions: Optional[bool] = None,
+                output_hidden_states: Optional[bool] = None, output_projector_features: Optional[bool] = None,
+                return_dict: Optional[bool] = None) -> Union[Tuple, PrismaticCausalLMOutputWithPast]:
+        """Multimodal forward (modeling_prismatic.py:362-415): returns fp32 logits [B, 256+L, vocab] and, when `labels`
+        are given, the shifted mean cross-entropy over the valid tokens (HF CausalLM loss). Inference only in this
+        round: gradients, `inputs_embeds`, `output_attentions` and `output_hidden_states` are not provided."""
+        if inputs_embeds is not None or output_attentions or output_hidden_states:
+            raise NotImplementedError("inputs_embeds / output_attentions / output_hidden_states are not on the HIP path")
+        if input_ids is None or pixel_values is None:
+            raise ValueError("Invalid PrismaticForConditionalGeneration `forward()` call: need input_ids and pixel_values")
+        if input_ids.shape[0] != pixel_values.shape[0]:
+            raise ValueError("Non-homogenous batch of (text, image) input -- forward() does not support mixed batches!")
+        if past_key_values is not None:
+            raise NotImplementedError("cached generation is driven by predict_action()/generate() on this path")
+        from ...forward_full import forward_all_rows
+        loss, logits, proj = forward_all_rows(self, input_ids, attention_mask, pixel_values, labels)
+        out = PrismaticCausalLMOutputWithPast(loss=loss, logits=logits,
+                                              projector_features=proj if output_projector_features else None)
+        if return_dict is False:
+            return out.to_tuple()
+        return out
+
+    __call__ = forward
+
+    # ---- greedy generation ----
+    @torch.no_grad()
+    def generate(self, input_ids: torch.LongTensor, max_new_tokens: int = 7, pixel_values: Optional[torch.Tensor] = None,
+                 attention_mask: Optional[torch.Tensor] = None, do_sample: bool = False, use_cache: bool = True,
+                 **_: Any) -> torch.LongTensor:
+        """Greedy decoding, returns [B, L + max_new_tokens] like GenerationMixin (prompt ‖ new tokens). `use_cache` is
+        accepted and ignored: the KV cache is always used (use_cache=False in the fork's demo re-runs the vision towers
+        7 times, run_openvla_demo.py:43 — same result, 7× the work)."""
+        if do_sample:
+            raise NotImplementedError("only greedy decoding (do_sample=False) is on the HIP path")
+        if pixel_values is None:
+            raise ValueError("generate() needs pixel_values")
+        if attention_mask is not None and not bool(attention_mask.bool().all()):
+            raise NotImplementedError("padded prompts are not supported in generate(); batch equal-length prompts")
+        B, L = input_ids.shape
+        if max_new_tokens != 7:
+            eng = OpenVLAEngine(self.weights, B, L, n_new=max_new_tokens)
+        else:
+            eng = self.engine(B, L)
+        new = eng.generate(input_ids.to(self.device), pixel_values.to(self.device))
+        return torch.cat([input_ids.to(self.device), new], dim=1)
+
+
+class OpenVLAForActionPrediction(PrismaticForConditionalGeneration):
+    config_class = OpenVLAConfig
+
+    def __init__(self, config: OpenVLAConfig, device: Union[str, torch.device] = "cuda:0",
+                 dims: Optional[VLADims] = None) -> None:
+        super().__init__(config, device, dims)
+        self.norm_stats = config.norm_stats
+        self.bins = np.linspace(-1, 1, config.n_action_bins)
+        self.bin_centers = (self.bins[:-1] + self.bins[1:]) / 2.0
+        # de-tokenisation vocabulary: the padded "multiple of 64" rows are not action tokens (reference :503-504)
+        self.vocab_size = self.dims.vocab - config.pad_to_multiple_of
+
+    def predict_action(self, input_ids: Optional[torch.LongTensor] = None, unnorm_key: Optional[str] = None,
+                       **kwargs: Any) -> np.ndarray:
+        """ids → 7 greedy action tokens → bin centres → un-normalised 7-DoF action (reference :506-536)."""
+        input_ids = input_ids.to(self.device)
+        if not torch.all(input_ids[:, -1] == 29871):
+            tail = torch.full((input_ids.shape[0], 1), 29871, dtype=torch.long, device=self.device)
+            input_ids = torch.cat((input_ids, tail), dim=1)
+            if kwargs.get("attention_mask") is not None:
+                m = kwargs["attention_mask"].to(self.device)
+                kwargs["attention_mask"] = torch.cat((m, torch.ones_like(m[:, :1])), dim=1)
+        n = self.get_action_dim(unnorm_key)
+        generated = self.generate(input_ids, max_new_tokens=n, **kwargs)
+        token_ids = generated[:, -n:].cpu().numpy()
+        discretized = np.clip(self.vocab_size - token_ids - 1, a_min=0, a_max=self.bin_centers.shape[0] - 1)
+        normalized = self.bin_centers[discretized]
+        stats = self.get_action_stats(unnorm_key)
+        mask = stats.get("mask", np.ones_like(stats["q01"], dtype=bool))
+        hi, lo = np.array(stats["q99"]), np.array(stats["q01"])
+        actions = np.where(mask, 0.5 * (normalized + 1) * (hi - lo) + lo, normalized)
+        return actions[0] if actions.shape[0] == 1 else actions
+
+    @staticmethod
+    def _check_unnorm_key(norm_stats: Dict[str, Dict[str, Any]], unnorm_key: Optional[str]) -> str:
+        if unnorm_key is None:
+            assert len(norm_stats) == 1, (
+                f"Your model was trained on more than one dataset, please pass a `unnorm_key` from the following "
+                f"options to choose the statistics used for un-normalizing actions: {norm_stats.keys()}")
+            unnorm_key = next(iter(norm_stats.keys()))
+        assert unnorm_key in norm_stats, (
+            f"The `unnorm_key` you chose is not in the set of available dataset statistics, please choose from: "
+            f"{norm_stats.keys()}")
+        return unnorm_key
+
+    def get_action_dim(self, unnorm_key: Optional[str] = None) -> int:
+        return len(self.norm_stats[self._check_unnorm_key(self.norm_stats, unnorm_key)]["action"]["q01"])
+
+    def get_action_stats(self, unnorm_key: Optional[str] = None) -> Dict[str, Any]:
+        return self.norm_stats[self._check_unnorm_key(self.norm_stats, unnorm_key)]["action"]

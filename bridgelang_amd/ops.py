@@ -41,10 +41,11 @@ def _rows(t: torch.Tensor, what: str) -> int:
 
 class Op:
     """A prepared call into libbridgelang_hip.so. Keeps its tensors alive."""
-    __slots__ = ("name", "fn", "args", "keep")
+    __slots__ = ("name", "fn", "args", "keep", "flops", "bytes")
 
-    def __init__(self, name: str, fn, args: tuple, keep: tuple):
+    def __init__(self, name: str, fn, args: tuple, keep: tuple, flops: float = 0.0, nbytes: float = 0.0):
         self.name, self.fn, self.args, self.keep = name, fn, args, keep
+        self.flops, self.bytes = flops, nbytes   # ALGORITHMIC work of this launch (bench.py roofline accounting)
 
     def run(self, stream: Optional[int] = None) -> None:
         rc = self.fn(*self.args, stream if stream is not None else _stream())
@@ -65,11 +66,12 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, epilogue: int = EP
          bias: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
          res: Optional[torch.Tensor] = None, res_row_mod: int = 0,
          out_map: Optional[Tuple[int, int, int]] = None, N: Optional[int] = None,
-         skinny: Optional[bool] = None, run: bool = True) -> Op:
+         skinny: Optional[bool] = None, algo_nk: Optional[Tuple[int, int]] = None, run: bool = True) -> Op:
     """out = epilogue(A @ W.T).  A [M,K], W [N,K] (nn.Linear layout), out [rows, N] (N/2 for SWIGLU; fp32 for F32).
 
     `out_map=(group, stride, offset)` remaps output rows (see bl_gemm_desc). `N` restricts to the first N weight rows.
     `skinny=None` picks the weight-streaming kernel automatically for M <= 16 when it supports K.
+    `algo_nk=(N, K)` gives the un-padded logical sizes for FLOP accounting when N or K carry zero padding.
     """
     lib = _lib.load()
     _bf16(A, "A"); _bf16(W, "W")
@@ -107,7 +109,11 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, epilogue: int = EP
         use_skinny = (M <= 16 and K in (512, 1024, 1536, 4096, 5120, 11008, 13824)
                       and epilogue in (EPI_NONE, EPI_RES, EPI_SWIGLU, EPI_F32, EPI_F32_BF16R))
     fn = lib.bl_gemm_skinny_bf16 if use_skinny else lib.bl_gemm_bf16
-    op = Op("bl_gemm_skinny_bf16" if use_skinny else "bl_gemm_bf16", fn, (C.byref(d),), (d, *keep))
+    # algorithmic work: logical FLOPs; bytes = each operand once + the output once
+    esz = 4 if epilogue in (EPI_F32, EPI_F32_BF16R) else 2
+    op = Op("bl_gemm_skinny_bf16" if use_skinny else "bl_gemm_bf16", fn, (C.byref(d),), (d, *keep),
+            flops=2.0 * M * (algo_nk[0] if algo_nk else N) * (algo_nk[1] if algo_nk else K),
+            nbytes=2.0 * (M * K + N * K) + esz * M * n_out)
     if run:
         op.run()
     return op
@@ -222,6 +228,21 @@ def argmax(logits: torch.Tensor, out: torch.Tensor, run: bool = True) -> Op:
     rows, n = logits.shape
     op = Op("bl_argmax_f32", lib.bl_argmax_f32, (logits.data_ptr(), _rows(logits, "logits"), rows, n, out.data_ptr()),
             (logits, out))
+    if run:
+        op.run()
+    return op
+
+
+def cross_entropy(logits: torch.Tensor, targets: torch.Tensor, row_loss: torch.Tensor, mean_and_count: torch.Tensor,
+                  ignore_index: int = -100, run: bool = True) -> Op:
+    """Per-row CE over fp32 logits [rows, n] against int64 targets [rows] (already shifted); mean over valid rows."""
+    lib = _lib.load()
+    if logits.dtype != torch.float32 or targets.dtype != torch.int64 or row_loss.dtype != torch.float32:
+        raise TypeError("cross_entropy: logits/row_loss fp32, targets int64")
+    rows, n = logits.shape
+    op = Op("bl_cross_entropy_f32", lib.bl_cross_entropy_f32,
+            (logits.data_ptr(), _rows(logits, "logits"), rows, n, targets.data_ptr(), ignore_index,
+             row_loss.data_ptr(), mean_and_count.data_ptr()), (logits, targets, row_loss, mean_and_count))
     if run:
         op.run()
     return op

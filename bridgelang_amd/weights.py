@@ -175,6 +175,12 @@ class Placement:
     ld: int
 
 
+def _block_view(pl: "Placement") -> torch.Tensor:
+    """[rows, cols] strided view of a placement (as_strided offsets are absolute within the storage)."""
+    flat = pl.dst.view(-1)
+    return torch.as_strided(flat, (pl.rows, pl.cols), (pl.ld, 1), flat.storage_offset() + pl.offset)
+
+
 class Arena:
     """One flat bf16 allocation carved into 256-byte aligned tensors (flat parameter storage)."""
 
@@ -278,7 +284,7 @@ class VLAWeights:
             if tuple(src.shape) != spec.shape:
                 raise ValueError(f"{spec.name}: expected {spec.shape}, got {tuple(src.shape)}")
             pl = self.placements[spec.name]
-            dst = torch.as_strided(pl.dst.view(-1), (pl.rows, pl.cols), (pl.ld, 1), pl.offset)
+            dst = _block_view(pl)
             dst.copy_(src.reshape(pl.rows, pl.cols).to(device=dst.device, dtype=torch.bfloat16))
         if strict and missing:
             raise KeyError(f"state dict is missing {len(missing)} tensors, e.g. {missing[:3]}")
@@ -289,7 +295,7 @@ class VLAWeights:
         out = {}
         for spec in tensor_specs(self.dims):
             pl = self.placements[spec.name]
-            src = torch.as_strided(pl.dst.view(-1), (pl.rows, pl.cols), (pl.ld, 1), pl.offset)
+            src = _block_view(pl)
             out[spec.name] = src.clone().reshape(spec.shape)
         return out
 

@@ -128,6 +128,12 @@ int bl_embed_splice_bf16(const int64_t* ids, int32_t B, int32_t L, const bl_bf16
 /* Row-wise argmax of fp32 logits [rows, n] (first maximal index, as torch.argmax); out int64 [rows]. */
 int bl_argmax_f32(const float* logits, int64_t ld, int32_t rows, int32_t n, int64_t* out, void* stream);
 
+/* Shifted causal-LM cross-entropy (HF LlamaForCausalLM loss; labels prepared by the caller as `targets[row]` =
+ * label of the NEXT position, -100 = ignore; base_strategy.py:287-297 consumes `output.loss`). row_loss[rows] receives
+ * the per-row loss (0 where ignored); mean_and_count[0] = mean over valid rows, [1] = number of valid rows. */
+int bl_cross_entropy_f32(const float* logits, int64_t ld, int32_t rows, int32_t n, const int64_t* targets,
+                         int64_t ignore_index, float* row_loss, float* mean_and_count, void* stream);
+
 /* ---- vision glue ------------------------------------------------------------------------------------------- */
 /* pixel_values [B, 6, 224, 224] bf16 (processing_prismatic.py:128-145 layout) → 14x14 patch rows for one tower:
  * out[b*256 + py*16 + px, c*196 + i*14 + j] = pixel_values[b, chan0 + c, py*14 + i, px*14 + j]; columns 588..ld-1

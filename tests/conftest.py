@@ -11,6 +11,8 @@ if str(ROOT) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    from oracle import pick_threads
+    pick_threads()   # 1 thread on virtualised hosts (OpenMP barriers cost ~100 ms there), all cores on real ones
 
 
 @pytest.fixture(scope="session")
