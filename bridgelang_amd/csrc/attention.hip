@@ -182,17 +182,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   }
 }
 
-// ---- decode: one wave per (batch, head), single query row, head_dim 128. Lane = (key group kg = lane>>4, 16-byte
-// chunk dc = lane&15): every wave-instruction reads 4 whole 256-byte K (or V) rows. ----
+// ---- decode: one workgroup (4 waves) per (batch, head), single query row, head_dim 128 ----
+// HBM-bound (reads the head's K and V rows once: 2·Skv·256 B). Lane = (key slot ks = lane>>4, 16-byte chunk dc =
+// lane&15), so one wave-instruction reads 4 whole 256-byte rows; the 4 waves interleave 16-key groups, and every
+// wave keeps 4 independent row loads in flight. Scores go through LDS once; the softmax statistics are recomputed by
+// every wave (Skv ≤ 2048 floats), the PV partials of the 4 waves are summed through LDS.
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
   constexpr int MAXKV = 2048;   // head_dim is fixed at 128 (16 lanes × 16 B per row)
-  __shared__ float sc[4][MAXKV];
+  __shared__ float sc[MAXKV];
+  __shared__ float part[4][128];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int bh = blockIdx.x * 4 + wave;
-  if (bh >= p.B * p.H) return;
+  const int bh = blockIdx.x;
   const int b = bh / p.H, h = bh - b * p.H;
-  const int kg = lane >> 4, dc = lane & 15;
-  float* s = sc[wave];
+  const int ks = lane >> 4, dc = lane & 15;
 
   float qv[8];
   {
@@ -200,57 +202,73 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { qv[2 * i] = bflo(t[i]); qv[2 * i + 1] = bfhi(t[i]); }
   }
-  const uint16_t* kbase = p.k + (long)b * p.k_bs + (long)h * p.k_hs;
-  const uint16_t* vbase = p.v + (long)b * p.v_bs + (long)h * p.v_hs;
+  const uint16_t* kbase = p.k + (long)b * p.k_bs + (long)h * p.k_hs + dc * 8;
+  const uint16_t* vbase = p.v + (long)b * p.v_bs + (long)h * p.v_hs + dc * 8;
   const uint8_t* mrow = p.mask ? p.mask + (long)b * p.mask_bs : nullptr;
   const int n = p.Skv;
 
-  // scores
-  for (int k0 = 0; k0 < n; k0 += 4) {
-    const int key = k0 + kg;
-    float d = 0.f;
-    if (key < n) {
-      const u32x4_t t = *(const u32x4_t*)(kbase + (long)key * p.k_rs + dc * 8);
+  // ---- scores: groups of 64 keys per workgroup iteration; wave w takes keys g*64 + w*16 + j*4 + ks, j = 0..3 ----
+  for (int g0 = 0; g0 < n; g0 += 64) {
+    u32x4_t kq[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) d += qv[2 * i] * bflo(t[i]) + qv[2 * i + 1] * bfhi(t[i]);
+    for (int j = 0; j < 4; ++j) {
+      const int key = g0 + wave * 16 + j * 4 + ks;
+      kq[j] = (u32x4_t){0u, 0u, 0u, 0u};
+      if (key < n) kq[j] = *(const u32x4_t*)(kbase + (long)key * p.k_rs);
     }
-    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
-    if (dc == 0 && key < n) s[key] = (mrow && mrow[key] == 0) ? -INFINITY : d * p.scale_log2e;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = g0 + wave * 16 + j * 4 + ks;
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d += qv[2 * i] * bflo(kq[j][i]) + qv[2 * i + 1] * bfhi(kq[j][i]);
+      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+      if (dc == 0 && key < n) sc[key] = (mrow && mrow[key] == 0) ? -INFINITY : d * p.scale_log2e;
+    }
   }
-  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible to its own reads
-  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
+  // ---- softmax statistics (every wave, redundantly; identical results) ----
   float mx = -INFINITY;
-  for (int i = lane; i < n; i += 64) mx = fmaxf(mx, s[i]);
+  for (int i = lane; i < n; i += 64) mx = fmaxf(mx, sc[i]);
   mx = wave_max(mx);
   const float m_use = (mx == -INFINITY) ? 0.f : mx;
   float l = 0.f;
-  for (int i = lane; i < n; i += 64) {
-    const float e = __builtin_amdgcn_exp2f(s[i] - m_use);
-    l += e;
-    s[i] = rbf(e);
-  }
+  for (int i = lane; i < n; i += 64) l += __builtin_amdgcn_exp2f(sc[i] - m_use);
   l = wave_sum(l);
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-  __builtin_amdgcn_wave_barrier();
 
+  // ---- PV: same key assignment; P rounded to bf16 as in the prefill kernel ----
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < n; k0 += 4) {
-    const int key = k0 + kg;
-    if (key < n) {
-      const float pk = s[key];
-      const u32x4_t t = *(const u32x4_t*)(vbase + (long)key * p.v_rs + dc * 8);
+  for (int g0 = 0; g0 < n; g0 += 64) {
+    u32x4_t vq[4];
+    float pk[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { acc[2 * i] += pk * bflo(t[i]); acc[2 * i + 1] += pk * bfhi(t[i]); }
+    for (int j = 0; j < 4; ++j) {
+      const int key = g0 + wave * 16 + j * 4 + ks;
+      vq[j] = (u32x4_t){0u, 0u, 0u, 0u};
+      pk[j] = 0.f;
+      if (key < n) {
+        vq[j] = *(const u32x4_t*)(vbase + (long)key * p.v_rs);
+        pk[j] = rbf(__builtin_amdgcn_exp2f(sc[key] - m_use));
+      }
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc[2 * i] += pk[j] * bflo(vq[j][i]); acc[2 * i + 1] += pk[j] * bfhi(vq[j][i]); }
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) { acc[i] += __shfl_xor(acc[i], 16, 64); acc[i] += __shfl_xor(acc[i], 32, 64); }
-  if (kg == 0) {
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
-    u32x4_t w;
+  if (ks == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = pack2bf(acc[2 * i] * inv, acc[2 * i + 1] * inv);
-    *(u32x4_t*)(p.o + (long)b * p.o_bs + (long)h * p.o_hs + dc * 8) = w;
+    for (int i = 0; i < 8; ++i) part[wave][dc * 8 + i] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {       // wave 0: lane handles 2 output dims
+    const int d0 = lane * 2;
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    const float o0 = (part[0][d0] + part[1][d0] + part[2][d0] + part[3][d0]) * inv;
+    const float o1 = (part[0][d0 + 1] + part[1][d0 + 1] + part[2][d0 + 1] + part[3][d0 + 1]) * inv;
+    *(uint32_t*)(p.o + (long)b * p.o_bs + (long)h * p.o_hs + d0) = pack2bf(o0, o1);
   }
 }
 
@@ -300,7 +318,7 @@ extern "C" int bl_attention_decode_bf16(const bl_attn_desc* d, void* stream) {
   if (rc != BL_OK) return rc;
   if (d->head_dim != 128 || d->Sq != 1 || d->Skv > 2048) return BL_E_SHAPE;
   if (((uintptr_t)d->o) & 15) return BL_E_ALIGN;
-  hipLaunchKernelGGL(attn_decode_kernel, dim3((d->B * d->H + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(attn_decode_kernel, dim3(d->B * d->H), dim3(256), 0, (hipStream_t)stream, a);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

@@ -1,97 +1,114 @@
 // gemm_bf16.hip — bf16 NT GEMM on gfx950 MFMA with fused epilogues:  C[M,N] = epi(A[M,K] · W[N,K]^T)
 //
 // Design (MI355X-first):
-//   * both operands are K-contiguous (activations [M,K], nn.Linear weights [N,K]) so tiles are staged HBM→LDS with
-//     LDS-DMA (`buffer_load_dwordx4 … lds`, 1 KiB per wave-instruction = 8 rows × 128 B of a BK=64 tile). The buffer
-//     descriptor's bounds check zero-fills rows past M / N, so ragged M (e.g. 16·261) needs no host padding.
-//   * LDS-DMA writes lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address
-//     (16-byte chunk c of row r is fetched from chunk c ^ (r & 7)) and undone on the ds_read_b128 side.
+//   * activations A[M,K] are row-major; weights are fragment-major (bl_pack_weight_bf16: one contiguous KiB per
+//     16-row × 32-k MFMA operand). Tiles are staged HBM→LDS with LDS-DMA (`buffer_load_dwordx4 … lds`, 1 KiB per
+//     wave-instruction). The buffer descriptor's bounds check zero-fills rows past M / weight tiles past N, so ragged M
+//     (e.g. 16·261) needs no host padding.
+//   * LDS-DMA writes lane-linear. Weight blocks therefore land already in ds_read_b128 order (address = block + 16·lane:
+//     conflict-free, no swizzle). Activation rows (128 B per row per K-step) get the bank-conflict swizzle on the
+//     per-lane SOURCE address (chunk c of row r is fetched from chunk c ^ (r & 7)) and undone on the read side.
 //   * MFMA is v_mfma_f32_16x16x32_bf16 computed TRANSPOSED: the weight tile is the "A" operand and the activation
 //     tile the "B" operand, so a lane ends up holding 4 consecutive output columns n of one row m → 8-byte stores
 //     and vector loads of bias / LayerScale / residual in the epilogue.
 //   * 1-D grid remapped so that each XCD (private L2) receives a contiguous run of tiles, walked in groups of
 //     GROUP_M row-tiles so concurrently resident tiles share weight panels.
+//
+// Two kernels:
+//   gemm128_kernel — 128×128×64 tile, 4 waves (64×64 each), 2 workgroups/CU, one vmcnt(0)+barrier per K-step. Small or
+//                    skinny problems, and the ragged tail of big ones.
+//   gemm256_kernel — 256×256×64 tile, 8 waves (128(m)×64(n) each), 128 KiB LDS = 2 stages, 1 workgroup/CU. Each K-tile
+//                    is staged as four 16-KiB HALF-TILES (X0/X1 = the two 64-row halves of every wave's activation
+//                    rows, Y0/Y1 = the two 32-row halves of every wave's weight rows) and consumed in four PHASES of 16
+//                    MFMAs (output quadrants (0,0) (0,1) (1,1) (1,0)). Per phase: issue one half-tile of LDS-DMA for a
+//                    later K-tile, prefetch the NEXT phase's fragments LDS→VGPR, run this phase's MFMAs, counted
+//                    `s_waitcnt vmcnt(4)` (two half-tiles stay in flight across the barrier — never 0 in the loop),
+//                    ONE raw s_barrier. Every half-tile is issued ≥ 3 phases before its first read.
 #include "gemm_common.h"
+#include <stdlib.h>
 
 namespace bl_gemm_bf16_impl {
 using namespace blgemm;
 
-
-constexpr int BK = 64;          // bf16 elements per K-step = 128 B per tile row
+constexpr int BK = 64;          // bf16 elements per K-step = 128 B per activation-tile row
 constexpr int ROW_BYTES = 128;
 constexpr int GROUP_M = 8;
 
-// BM × BN output tile (BM activation rows, BN weight rows), WM × WN waves.
-template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
-#if defined(__HIP_DEVICE_COMPILE__)   // __amdgpu_buffer_rsrc_t does not exist in the host pass; an ill-formed host body
-                                     // silently drops the kernel's host handle (undefined symbol at dlopen)
-  constexpr int NWAVE = WM * WN;
-  constexpr int TM = BM / WM, TN = BN / WN;      // per-wave tile
-  constexpr int MT = TM / 16, NT = TN / 16;      // MFMA tiles per wave
-  constexpr int PIECES_A = BM / 8, PIECES_W = BN / 8;   // 1-KiB LDS-DMA pieces per K-step
-  constexpr int PA = PIECES_A / NWAVE, PW = PIECES_W / NWAVE;
-  constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES, BUF_BYTES = A_BYTES + W_BYTES;
-  static_assert(PIECES_A % NWAVE == 0 && PIECES_W % NWAVE == 0, "pieces must divide over waves");
+// linear tile index → (row tile, column tile): groups of GROUP_M row-tiles walked column by column
+__device__ __forceinline__ void lin_to_tile(const GemmArgs& p, int lin, int& tm, int& tn) {
+  const int width = GROUP_M * p.tiles_n, grp = lin / width, first = grp * GROUP_M;
+  const int gsz = min(p.tiles_m - first, GROUP_M), rem = lin - grp * width;
+  tm = first + rem % gsz;
+  tn = rem / gsz;
+}
 
+__device__ __forceinline__ void tile_coords(const GemmArgs& p, int& tm, int& tn) {
+  // XCD-contiguous ordering over the LAUNCHED blocks (speed only; any bijective mapping is correct). The grid may
+  // cover only the first gridDim.x tiles of the tiles_m x tiles_n grid (whole rounds; the tail goes to gemm128).
+  const int nwg = gridDim.x;
+  const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int width = GROUP_M * p.tiles_n, grp = lin / width, first = grp * GROUP_M;
+  const int gsz = min(p.tiles_m - first, GROUP_M), rem = lin - grp * width;
+  tm = first + rem % gsz;
+  tn = rem / gsz;
+}
+
+#define BL_GLDS(RS, LDSP, VOFF, SOFF) __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, LDS_PTR(LDSP), 16, VOFF, SOFF, 0, 0)
+
+// ======================================================================================================================
+// 128 × 128 tile
+// ======================================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm128_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // __amdgpu_buffer_rsrc_t does not exist in the host pass; an ill-formed host body
+                                      // silently drops the kernel's host handle (undefined symbol at dlopen)
+  constexpr int BM = 128, BN = 128, WN = 2, NWAVE = 4;
+  constexpr int TM = 64, TN = 64, MT = 4, NT = 4;
+  constexpr int A_BYTES = BM * ROW_BYTES, BUF_BYTES = A_BYTES + BN * ROW_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 × BUF_BYTES
 
-  // ---- tile coordinates: XCD-contiguous + grouped ordering (speed only; any mapping is correct) ----
-  const int nwg = p.tiles_m * p.tiles_n;
-  int lin;
-  {
-    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  int tm, tn, m0, n0;
+  if (p.tail_base >= 0) {   // tail mode: 4 small tiles per leftover 256x256 tile of the big kernel's grid
+    lin_to_tile(p, p.tail_base + (blockIdx.x >> 2), tm, tn);
+    m0 = tm * 256 + ((blockIdx.x >> 1) & 1) * 128;
+    n0 = tn * 256 + (blockIdx.x & 1) * 128;
+  } else {
+    tile_coords(p, tm, tn);
+    m0 = tm * BM, n0 = tn * BN;
   }
-  int tm, tn;
-  {
-    const int width = GROUP_M * p.tiles_n, grp = lin / width, first = grp * GROUP_M;
-    const int gsz = min(p.tiles_m - first, GROUP_M), rem = lin - grp * width;
-    tm = first + rem % gsz;
-    tn = rem / gsz;
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  const int kt32 = p.K >> 5;
 
-  // ---- buffer descriptors (bounds check zero-fills rows ≥ M / ≥ N) ----
   const unsigned a_bytes = (unsigned)min((long)p.M * p.lda * 2, 0xffffffffL);
-  const unsigned w_bytes = (unsigned)min((long)p.N * p.ldw * 2, 0xffffffffL);
+  const unsigned w_bytes = (unsigned)min((long)p.N * p.K * 2, 0xffffffffL);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
 
-  // per-lane source offsets of this wave's pieces (k-independent part); lane → (row = lane>>3, chunk = lane&7)
-  const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;   // swizzled source chunk
-  unsigned voffA[PA], voffW[PW];
+  // activation pieces: 16 × (8 rows × 128 B); wave takes pieces j*4 + wave. lane → (row = lane>>3, chunk = lane&7)
+  const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
+  unsigned voffA[4], voffW[4];
 #pragma unroll
-  for (int j = 0; j < PA; ++j) {
-    const int r = (j * NWAVE + wave) * 8 + prow;
-    voffA[j] = (unsigned)(((long)(m0 + r) * p.lda) * 2 + pchunk * 16);
-  }
+  for (int j = 0; j < 4; ++j) voffA[j] = (unsigned)(((long)(m0 + (j * NWAVE + wave) * 8 + prow) * p.lda) * 2 + pchunk * 16);
+  // weight blocks: 8 n-tiles × 2 k-steps; wave takes n-tiles 2*wave, 2*wave+1 (both k-steps: 2 KiB contiguous each)
 #pragma unroll
-  for (int j = 0; j < PW; ++j) {
-    const int r = (j * NWAVE + wave) * 8 + prow;
-    voffW[j] = (unsigned)(((long)(n0 + r) * p.ldw) * 2 + pchunk * 16);
-  }
+  for (int j = 0; j < 4; ++j)
+    voffW[j] = (unsigned)(((long)(n0 / 16 + 2 * wave + (j >> 1)) * kt32 + (j & 1)) * 1024 + lane * 16);
 
-  // (a macro, not a lambda: a lambda inside a __global__ template makes hipcc's HOST pass drop the kernel handle)
-#define BL_STAGE(BUF, KT)                                                                                             \
-  do {                                                                                                                \
-    const int koff__ = (KT) * (BK * 2);                                                                               \
-    char* base__ = smem + (BUF) * BUF_BYTES;                                                                          \
-    _Pragma("unroll") for (int j = 0; j < PA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                          \
-        rsA, LDS_PTR(base__ + (j * NWAVE + wave) * 1024), 16, voffA[j], koff__, 0, 0);                                \
-    _Pragma("unroll") for (int j = 0; j < PW; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                          \
-        rsW, LDS_PTR(base__ + A_BYTES + (j * NWAVE + wave) * 1024), 16, voffW[j], koff__, 0, 0);                      \
+#define BL_STAGE(BUF, KT)                                                                                   \
+  do {                                                                                                      \
+    char* base__ = smem + (BUF) * BUF_BYTES;                                                                \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) BL_GLDS(rsA, base__ + (j * NWAVE + wave) * 1024, voffA[j], (KT) * 128); \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                           \
+        BL_GLDS(rsW, base__ + A_BYTES + ((2 * wave + (j >> 1)) * 2 + (j & 1)) * 1024, voffW[j], (KT) * 2048); \
   } while (0)
 
-  // ---- fragment read offsets ----
   const int l15 = lane & 15, lg = lane >> 4;
-  const int c0 = lg ^ (lane & 7);                 // swizzled chunk of k-step 0 (k-step 1: c0 ^ 4)
-  const int offA = (wm * TM + l15) * ROW_BYTES;   // activation tile ("B" operand of the MFMA)
-  const int offW = A_BYTES + (wn * TN + l15) * ROW_BYTES;
+  const int c0 = lg ^ (lane & 7);
+  const int offA = (wm * TM + l15) * ROW_BYTES;
+  const int offW = A_BYTES + (wn * 4) * 2048 + lane * 16;   // block (wn*4 + i)*2 + ks
 
   f32x4_t acc[NT][MT];
 #pragma unroll
@@ -101,8 +118,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
 
   const int nk = p.K / BK;
   BL_STAGE(0, 0);
-  __syncthreads();   // includes vmcnt(0): tile 0 landed
-
+  __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) BL_STAGE(cur ^ 1, kt + 1);
@@ -112,7 +128,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
       const int cb = (c0 ^ (ks * 4)) << 4;
       bf16x8_t wf[NT], af[MT];
 #pragma unroll
-      for (int i = 0; i < NT; ++i) wf[i] = *(const bf16x8_t*)(base + offW + i * 16 * ROW_BYTES + cb);
+      for (int i = 0; i < NT; ++i) wf[i] = *(const bf16x8_t*)(base + offW + i * 2048 + ks * 1024);
 #pragma unroll
       for (int j = 0; j < MT; ++j) af[j] = *(const bf16x8_t*)(base + offA + j * 16 * ROW_BYTES + cb);
 #pragma unroll
@@ -121,38 +137,204 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs p) {
         for (int j = 0; j < MT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();   // next tile landed (vmcnt(0)) and everyone is done reading `cur`
+    __syncthreads();
   }
-
-  // ---- epilogue: lane holds D[n = 4*lg + r][m = l15] of each 16×16 tile ----
+#undef BL_STAGE
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
-      const int n = n0 + wn * TN + i * 16 + lg * 4;
-      const int m = m0 + wm * TM + j * 16 + l15;
-      epilogue_store4<EPI>(p, m, n, acc[i][j]);
-    }
+    for (int j = 0; j < MT; ++j)
+      epilogue_store4<EPI>(p, m0 + wm * TM + j * 16 + l15, n0 + wn * TN + i * 16 + lg * 4, acc[i][j]);
 #endif
 }
 
-#undef BL_STAGE
+// ======================================================================================================================
+// 256 × 256 tile, half-tile LDS-DMA ring, 4 phases per K-tile
+// ======================================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 256, BN = 256;
+  constexpr int STAGE = 65536, W_OFF = 32768;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages × (32 KiB activations + 32 KiB weights)
+
+  int tm, tn;
+  tile_coords(p, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int kt32 = p.K >> 5, nk = p.K / BK;
+
+  const unsigned a_bytes = (unsigned)min((long)p.M * p.lda * 2, 0xffffffffL);
+  const unsigned w_bytes = (unsigned)min((long)p.N * p.K * 2, 0xffffffffL);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
+  // zero-record descriptors: every access is out of range → LDS gets zeros, no memory traffic (K-tiles past the end)
+  const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0, 0x00020000);
+
+  // ---- LDS-DMA source offsets. Half-tile X<mh>: rows {wm'*128 + mh*64 + 0..63}, wm' = 0,1 → 16 pieces of 8 rows;
+  //      this wave takes pieces 2*wave, 2*wave+1. Half-tile Y<nh>: for wn' = 0..3 the weight n-tiles wn'*4 + 2*nh + {0,1},
+  //      both k-steps → 16 KiB; this wave takes (wn' = wave>>1, n-tile 2*nh + (wave&1)), k-steps 0 and 1. ----
+  const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
+  unsigned voffX[2][2], voffY[2][2];
+  int ldsX[2][2], ldsY[2];
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pi = 2 * wave + j, row0 = (pi >> 3) * 128 + mh * 64 + (pi & 7) * 8;
+      voffX[mh][j] = (unsigned)(((long)(m0 + row0 + prow) * p.lda) * 2 + pchunk * 16);
+      ldsX[mh][j] = row0 * ROW_BYTES;
+    }
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    const int nt = (wave >> 1) * 4 + 2 * nh + (wave & 1);
+    voffY[nh][0] = (unsigned)((long)(n0 / 16 + nt) * kt32 * 1024 + lane * 16);
+    voffY[nh][1] = voffY[nh][0] + 1024;
+    ldsY[nh] = W_OFF + nt * 2048;
+  }
+#define ISSUE_X(MH, TILE)                                                                   \
+  do {                                                                                      \
+    const int t__ = (TILE);                                                                 \
+    const __amdgpu_buffer_rsrc_t rs__ = t__ < nk ? rsA : rsA0;                              \
+    char* b__ = smem + (t__ & 1) * STAGE;                                                   \
+    BL_GLDS(rs__, b__ + ldsX[MH][0], voffX[MH][0], t__ * 128);                              \
+    BL_GLDS(rs__, b__ + ldsX[MH][1], voffX[MH][1], t__ * 128);                              \
+  } while (0)
+#define ISSUE_Y(NH, TILE)                                                                   \
+  do {                                                                                      \
+    const int t__ = (TILE);                                                                 \
+    const __amdgpu_buffer_rsrc_t rs__ = t__ < nk ? rsW : rsW0;                              \
+    char* b__ = smem + (t__ & 1) * STAGE;                                                   \
+    BL_GLDS(rs__, b__ + ldsY[NH], voffY[NH][0], t__ * 2048);                                \
+    BL_GLDS(rs__, b__ + ldsY[NH] + 1024, voffY[NH][1], t__ * 2048);                         \
+  } while (0)
+
+  // ---- fragment reads ----
+  const int cb0 = (lg ^ (lane & 7)) << 4;                       // swizzled chunk of k-step 0; k-step 1 = cb0 ^ 64
+  const int offX = (wm * 128 + l15) * ROW_BYTES;                // + mh*8192 + i*2048
+  const int offY = W_OFF + wn * 8192 + lane * 16;               // + (2*nh + j)*2048 + ks*1024
+#define READ_X(DST, MH, SB)                                                                             \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+    DST[i * 2] = *(const bf16x8_t*)((SB) + offX + (MH) * 8192 + i * 2048 + cb0);                        \
+    DST[i * 2 + 1] = *(const bf16x8_t*)((SB) + offX + (MH) * 8192 + i * 2048 + (cb0 ^ 64));            \
+  }
+#define READ_Y(DST, NH, SB)                                                                             \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
+    DST[j * 2] = *(const bf16x8_t*)((SB) + offY + (2 * (NH) + j) * 2048);                               \
+    DST[j * 2 + 1] = *(const bf16x8_t*)((SB) + offY + (2 * (NH) + j) * 2048 + 1024);                    \
+  }
+#define MMA(XR, YR, MH, NH)                                                                             \
+  do {                                                                                                  \
+    __builtin_amdgcn_s_setprio(1);                                                                      \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
+          acc[2 * (NH) + j][4 * (MH) + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                    \
+              YR[j * 2 + ks], XR[i * 2 + ks], acc[2 * (NH) + j][4 * (MH) + i], 0, 0, 0);                \
+    __builtin_amdgcn_s_setprio(0);                                                                      \
+  } while (0)
+  // lgkmcnt(0): this phase's prefetch reads have returned (so a later LDS-DMA into the same half-tile cannot overtake
+  // them); vmcnt(4): all but the two youngest half-tiles have landed; the barrier publishes them to the other waves.
+#define PHASE_END(WAITVM)                                                         \
+  do {                                                                            \
+    if (WAITVM) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");       \
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       \
+    __builtin_amdgcn_s_barrier();                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+  } while (0)
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  bf16x8_t Xa[8], Xb[8], Ya[4], Yb[4];
+  char* const S0 = smem;
+  char* const S1 = smem + STAGE;
+
+  // ---- prologue: X0 Y0 Y1 X1 of tile 0 and X0 of tile 1; the first three must have landed ----
+  ISSUE_X(0, 0); ISSUE_Y(0, 0); ISSUE_Y(1, 0); ISSUE_X(1, 0); ISSUE_X(0, 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  READ_X(Xa, 0, S0);
+  READ_Y(Ya, 0, S0);
+
+  for (int t = 0; t < nk; t += 2) {
+    // ---- K-tile t (stage 0) ----
+    ISSUE_Y(0, t + 1); READ_Y(Yb, 1, S0);                    MMA(Xa, Ya, 0, 0); PHASE_END(1);
+    ISSUE_Y(1, t + 1); READ_X(Xb, 1, S0);                    MMA(Xa, Yb, 0, 1); PHASE_END(0);
+    ISSUE_X(1, t + 1); READ_Y(Ya, 0, S0);                    MMA(Xb, Yb, 1, 1); PHASE_END(1);
+    ISSUE_X(0, t + 2); READ_X(Xa, 0, S1); READ_Y(Yb, 0, S1); MMA(Xb, Ya, 1, 0); PHASE_END(1);
+    // ---- K-tile t+1 (stage 1); the two weight register sets have swapped roles ----
+    ISSUE_Y(0, t + 2); READ_Y(Ya, 1, S1);                    MMA(Xa, Yb, 0, 0); PHASE_END(1);
+    ISSUE_Y(1, t + 2); READ_X(Xb, 1, S1);                    MMA(Xa, Ya, 0, 1); PHASE_END(0);
+    ISSUE_X(1, t + 2); READ_Y(Yb, 0, S1);                    MMA(Xb, Ya, 1, 1); PHASE_END(1);
+    ISSUE_X(0, t + 3); READ_X(Xa, 0, S0); READ_Y(Ya, 0, S0); MMA(Xb, Yb, 1, 0); PHASE_END(1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // out-of-range tail loads must not outlive the wave's LDS
+#undef ISSUE_X
+#undef ISSUE_Y
+#undef READ_X
+#undef READ_Y
+#undef MMA
+#undef PHASE_END
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      epilogue_store4<EPI>(p, m0 + wm * 128 + j * 16 + l15, n0 + wn * 64 + i * 16 + lg * 4, acc[i][j]);
+#endif
+}
+#undef BL_GLDS
+
+template <int EPI>
+int set_lds_attr() {
+  static bool done = false;   // idempotent; a benign race only repeats the same calls
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * ROW_BYTES) != hipSuccess)
+      return BL_E_LAUNCH;
+    done = true;
+  }
+  return BL_OK;
+}
 
 template <int EPI>
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
-  constexpr int BM = 128, BN = 128, WM = 2, WN = 2;
+  constexpr int CUS = 256;              // MI355X: the 256x256 kernel runs one workgroup per CU
+  constexpr int LDS128 = 2 * 256 * ROW_BYTES, LDS256 = 2 * 65536;
+  if (set_lds_attr<EPI>() != BL_OK) return BL_E_LAUNCH;
   GemmArgs p = a;
-  p.tiles_m = (p.M + BM - 1) / BM;
-  p.tiles_n = (p.N + BN - 1) / BN;
-  const int lds = 2 * (BM + BN) * ROW_BYTES;
-  static bool attr_set = false;   // idempotent; a benign race only repeats the same call
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, EPI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return BL_E_LAUNCH;
-    attr_set = true;
+  static const char* force = getenv("BL_GEMM_TILE");   // "128" / "256": benchmarking aid
+  const int bm = (p.M + 255) / 256, bn = (p.N + 255) / 256, big_tiles = bm * bn;
+  bool big = big_tiles >= CUS && p.K >= 512;
+  if (force) big = force[0] == '2';
+  if (!big) {
+    p.tiles_m = (p.M + 127) / 128;
+    p.tiles_n = (p.N + 127) / 128;
+    hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(p.tiles_m * p.tiles_n), dim3(256), LDS128, s, p);
+    BL_CHECK_LAUNCH();
+    return BL_OK;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, EPI>), dim3(p.tiles_m * p.tiles_n), dim3(WM * WN * 64), lds, s, p);
+  // Whole rounds of 256 tiles on the pipelined kernel; a partial last round would leave most CUs idle for a full tile
+  // time, so its tiles are cut into 128x128 quarters and run by the small kernel (2 workgroups per CU) instead.
+  p.tiles_m = bm;
+  p.tiles_n = bn;
+  int main_tiles = big_tiles, tail = big_tiles % CUS;
+  if (tail != 0 && tail <= 192 && !force) main_tiles = big_tiles - tail; else tail = 0;
+  hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(main_tiles), dim3(512), LDS256, s, p);
+  if (tail) {
+    p.tail_base = main_tiles;
+    hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(tail * 4), dim3(256), LDS128, s, p);
+  }
   BL_CHECK_LAUNCH();
   return BL_OK;
 }
@@ -164,9 +346,8 @@ extern "C" int bl_gemm_bf16(const bl_gemm_desc* d, void* stream) {
   GemmArgs a;
   const int rc = fill_gemm_args(d, a);
   if (rc != BL_OK) return rc;
-  const int epi = d->epilogue;
   hipStream_t s = (hipStream_t)stream;
-  switch (epi) {
+  switch (d->epilogue) {
     case BL_EPI_NONE: return launch_gemm<BL_EPI_NONE>(a, s);
     case BL_EPI_BIAS: return launch_gemm<BL_EPI_BIAS>(a, s);
     case BL_EPI_BIAS_GELU: return launch_gemm<BL_EPI_BIAS_GELU>(a, s);

@@ -13,6 +13,7 @@ struct GemmArgs {
   int M, N, K;
   int res_row_mod, out_group, out_stride, out_offset;
   int tiles_m, tiles_n;
+  int tail_base;   // >= 0: this launch covers big (256x256) tiles tail_base.. of the tiles_m x tiles_n big-tile grid
 };
 
 __device__ __forceinline__ int out_row_of(const GemmArgs& p, int m) {
@@ -73,7 +74,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n,
 inline int fill_gemm_args(const bl_gemm_desc* d, GemmArgs& a) {
   if (!d || !d->A || !d->W || !d->C) return BL_E_ARG;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % 64) != 0 || (d->N % 16) != 0) return BL_E_SHAPE;
-  if ((d->lda % 8) || (d->ldw % 8) || d->lda < d->K || d->ldw < d->K) return BL_E_ALIGN;
+  if ((d->lda % 8) || d->lda < d->K || d->ldw != d->K) return BL_E_ALIGN;   // W is packed: no leading dimension
   if (!bl_aligned16(d->A) || !bl_aligned16(d->W) || (((uintptr_t)d->C) & 15)) return BL_E_ALIGN;
   const int epi = d->epilogue;
   if (epi == BL_EPI_SWIGLU) { if ((d->ldc % 2) || (d->N % 32)) return BL_E_ALIGN; }
@@ -86,6 +87,7 @@ inline int fill_gemm_args(const bl_gemm_desc* d, GemmArgs& a) {
   a.M = d->M; a.N = d->N; a.K = d->K;
   a.res_row_mod = d->res_row_mod; a.out_group = d->out_group; a.out_stride = d->out_stride; a.out_offset = d->out_offset;
   a.tiles_m = a.tiles_n = 0;
+  a.tail_base = -1;
   return BL_OK;
 }
 

@@ -209,6 +209,21 @@ __global__ __launch_bounds__(256) void masked_mean_kernel(const float* row_loss,
   }
 }
 
+// ---- weight packing: row-major [N, K] → MFMA-fragment-major [N/16][K/32][64 lanes][8] ----
+// One 16-byte chunk per thread: packed chunk (nt, ks, lane) = W[16*nt + (lane & 15)][32*ks + 8*(lane >> 4) .. +7], i.e.
+// exactly what lane `lane` feeds v_mfma_f32_16x16x32_bf16 for weight tile nt, k-step ks. Every (nt, ks) block is one
+// contiguous KiB, so decode streams weights with whole-line requests and LDS-DMA lands them already in read order.
+__global__ void pack_weight_kernel(const uint16_t* src, long ld, long n, long k, uint16_t* dst) {
+  const long ks_n = k >> 5;
+  const long total = (n >> 4) * ks_n * 64;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const long blk = i >> 6, ks = blk % ks_n, nt = blk / ks_n;
+    const long row = nt * 16 + (lane & 15), col = ks * 32 + (lane >> 4) * 8;
+    *(u32x4_t*)(dst + i * 8) = *(const u32x4_t*)(src + row * ld + col);
+  }
+}
+
 inline int grid_for(long total, int block) {
   long g = (total + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));   // cap at 256 CUs × 8 and grid-stride the rest
@@ -229,6 +244,16 @@ extern "C" int bl_fill_synth_bf16_2d(bl_bf16* dst, int64_t rows, int64_t cols, i
   BL_CHECK_LAUNCH();
   return BL_OK;
 }
+extern "C" int bl_pack_weight_bf16(const bl_bf16* src, int64_t ld, int64_t n, int64_t k, bl_bf16* dst, void* stream) {
+  if (!src || !dst) return BL_E_ARG;
+  if (n <= 0 || k <= 0 || (n % 16) || (k % 32) || ld < k) return BL_E_SHAPE;
+  if ((ld % 8) || !bl_aligned16(src) || !bl_aligned16(dst)) return BL_E_ALIGN;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(n * k / 8, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     (long)ld, (long)n, (long)k, dst);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
 extern "C" int bl_fill_synth_bf16(bl_bf16* dst, int64_t n, uint32_t seed, float mean, float scale, void* stream) {
   return bl_fill_synth_bf16_2d(dst, 1, n, n, seed, mean, scale, stream);
 }

@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import (AttnDesc, GemmDesc, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_F32, EPI_F32_BF16R, EPI_NONE,
                    EPI_RES, EPI_SWIGLU)
 
-__all__ = ["Op", "gemm", "layernorm", "rmsnorm", "attention", "attention_decode", "rope_kvcache", "embed_splice",
+__all__ = ["Op", "gemm", "pack_weight", "unpack_weight", "cross_entropy", "layernorm", "rmsnorm", "attention", "attention_decode", "rope_kvcache", "embed_splice",
            "argmax", "im2col_patch14", "write_prefix_tokens", "fill_synth", "run_all",
            "EPI_NONE", "EPI_BIAS", "EPI_BIAS_GELU", "EPI_BIAS_RES", "EPI_RES", "EPI_SWIGLU", "EPI_F32", "EPI_F32_BF16R"]
 
@@ -62,30 +62,51 @@ def run_all(ops: Sequence[Op]) -> None:
 
 
 # ---------------------------------------------------------------------------------------------------------------
+def pack_weight(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Linear-layout weight [N, K] (last dim contiguous) → fragment-major [N/16, K/32, 64, 8] (bl_pack_weight_bf16).
+    N % 16 == 0 and K % 32 == 0 (zero-pad first). Done once at load time."""
+    lib = _lib.load()
+    _bf16(w, "w")
+    N, K = w.shape
+    if out is None:
+        out = torch.empty(N // 16, K // 32, 64, 8, dtype=torch.bfloat16, device=w.device)
+    _lib.check(lib.bl_pack_weight_bf16(w.data_ptr(), _rows(w, "w"), N, K, _bf16(out, "out").data_ptr(), _stream()),
+               "bl_pack_weight_bf16")
+    return out
+
+
+def unpack_weight(wp: torch.Tensor) -> torch.Tensor:
+    """Inverse of pack_weight (torch glue; used only when exporting a state dict)."""
+    nt, ks = wp.shape[0], wp.shape[1]
+    return wp.view(nt, ks, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(nt * 16, ks * 32)
+
+
 def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, *,
          bias: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
          res: Optional[torch.Tensor] = None, res_row_mod: int = 0,
-         out_map: Optional[Tuple[int, int, int]] = None, N: Optional[int] = None,
+         out_map: Optional[Tuple[int, int, int]] = None,
          skinny: Optional[bool] = None, algo_nk: Optional[Tuple[int, int]] = None, run: bool = True) -> Op:
-    """out = epilogue(A @ W.T).  A [M,K], W [N,K] (nn.Linear layout), out [rows, N] (N/2 for SWIGLU; fp32 for F32).
+    """out = epilogue(A @ W.T).  A [M,K] row-major activations; W = PACKED weight [N/16, K/32, 64, 8] (pack_weight);
+    out [rows, N] (N/2 for SWIGLU; fp32 for F32*).
 
-    `out_map=(group, stride, offset)` remaps output rows (see bl_gemm_desc). `N` restricts to the first N weight rows.
+    `out_map=(group, stride, offset)` remaps output rows (see bl_gemm_desc).
     `skinny=None` picks the weight-streaming kernel automatically for M <= 16 when it supports K.
     `algo_nk=(N, K)` gives the un-padded logical sizes for FLOP accounting when N or K carry zero padding.
     """
     lib = _lib.load()
     _bf16(A, "A"); _bf16(W, "W")
+    if W.dim() != 4 or W.shape[2:] != (64, 8) or not W.is_contiguous():
+        raise ValueError(f"gemm: W must be a packed weight [N/16, K/32, 64, 8] (ops.pack_weight), got {tuple(W.shape)}")
     M, K = A.shape
-    n_rows, Kw = W.shape
+    N, Kw = W.shape[0] * 16, W.shape[1] * 32
     if Kw != K:
-        raise ValueError(f"gemm: K mismatch A{tuple(A.shape)} W{tuple(W.shape)}")
-    N = n_rows if N is None else N
+        raise ValueError(f"gemm: K mismatch A{tuple(A.shape)} W(packed) K={Kw}")
     want = torch.float32 if epilogue in (EPI_F32, EPI_F32_BF16R) else torch.bfloat16
     if out.dtype != want or not out.is_cuda:
         raise TypeError(f"gemm: out must be {want} on device")
     d = GemmDesc()
     d.A, d.lda = A.data_ptr(), _rows(A, "A")
-    d.W, d.ldw = W.data_ptr(), _rows(W, "W")
+    d.W, d.ldw = W.data_ptr(), K
     d.C, d.ldc = out.data_ptr(), _rows(out, "out")
     d.M, d.N, d.K, d.epilogue = M, N, K, epilogue
     keep = [A, W, out]
@@ -101,9 +122,8 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, epilogue: int = EP
     n_out = N // 2 if epilogue == EPI_SWIGLU else N
     if out.shape[1] < n_out:
         raise ValueError(f"gemm: out has {out.shape[1]} columns, needs {n_out}")
-    rows_needed = M if out_map is None else ((M - 1) // out_map[0]) * out_map[1] + min(out_map[1], out_map[0] + out_map[2])
-    if out.shape[0] < rows_needed and out_map is None:
-        raise ValueError(f"gemm: out has {out.shape[0]} rows, needs {rows_needed}")
+    if out_map is None and out.shape[0] < M:
+        raise ValueError(f"gemm: out has {out.shape[0]} rows, needs {M}")
     use_skinny = skinny
     if use_skinny is None:
         use_skinny = (M <= 16 and K in (512, 1024, 1536, 4096, 5120, 11008, 13824)

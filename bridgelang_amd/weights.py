@@ -167,18 +167,43 @@ def tensor_specs(d: VLADims) -> List[TensorSpec]:
 # ---- packed device layout --------------------------------------------------------------------------------------
 @dataclass
 class Placement:
-    """Where one HF tensor lives inside a packed device tensor: a [rows, cols] block at `offset` with leading dim `ld`."""
-    dst: torch.Tensor
+    """Where one HF tensor lives: a [rows, cols] block at element `offset` (leading dim `ld`) of either a plain
+    row-major device tensor (`dst`) or — for GEMM weights — of the logical [N, Kpad] matrix of a packed group."""
+    dst: Optional[torch.Tensor]
     offset: int
     rows: int
     cols: int
     ld: int
+    group: Optional["PackedGroup"] = None
 
 
-def _block_view(pl: "Placement") -> torch.Tensor:
+@dataclass
+class PackedGroup:
+    """One GEMM weight in fragment-major layout [N/16, Kpad/32, 64, 8] (include/bridgelang_hip.h, "weight layout")
+    together with the HF tensors that make up its logical [N, Kpad] matrix (q‖k‖v, interleaved gate/up, K padding)."""
+    packed: torch.Tensor
+    n: int
+    k: int
+    members: List[str] = field(default_factory=list)
+
+
+def _block_view(flat: torch.Tensor, pl: "Placement") -> torch.Tensor:
     """[rows, cols] strided view of a placement (as_strided offsets are absolute within the storage)."""
-    flat = pl.dst.view(-1)
     return torch.as_strided(flat, (pl.rows, pl.cols), (pl.ld, 1), flat.storage_offset() + pl.offset)
+
+
+def _pack(staging: torch.Tensor, out: torch.Tensor) -> None:
+    if staging.is_cuda:
+        from . import ops
+        ops.pack_weight(staging, out)          # bl_pack_weight_bf16
+    else:                                      # CPU: layout tests only (no kernels run on CPU)
+        n, k = staging.shape
+        out.view(n // 16, k // 32, 4, 16, 8).copy_(staging.view(n // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4))
+
+
+def _unpack(packed: torch.Tensor) -> torch.Tensor:
+    nt, ks = packed.shape[0], packed.shape[1]
+    return packed.view(nt, ks, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(nt * 16, ks * 32)
 
 
 class Arena:
@@ -217,7 +242,7 @@ class Arena:
 @dataclass
 class BlockW:
     norm1_w: torch.Tensor; norm1_b: torch.Tensor
-    qkv_w: torch.Tensor; qkv_b: torch.Tensor
+    qkv_w: torch.Tensor; qkv_b: torch.Tensor          # *_w: packed
     proj_w: torch.Tensor; proj_b: torch.Tensor
     ls1: Optional[torch.Tensor]
     norm2_w: torch.Tensor; norm2_b: torch.Tensor
@@ -229,7 +254,7 @@ class BlockW:
 @dataclass
 class TowerW:
     dims: TowerDims
-    patch_w: torch.Tensor      # [D, 640]
+    patch_w: torch.Tensor      # packed [D, 640]
     patch_b: torch.Tensor
     pos: torch.Tensor          # [256, D]
     prefix: Optional[torch.Tensor]   # [n_prefix, D] = cls ‖ registers
@@ -239,11 +264,11 @@ class TowerW:
 @dataclass
 class LayerW:
     ln1: torch.Tensor
-    qkv_w: torch.Tensor        # [3D, D]  q ‖ k ‖ v
+    qkv_w: torch.Tensor        # packed [3D, D]  q ‖ k ‖ v
     o_w: torch.Tensor
     ln2: torch.Tensor
-    gu_w: torch.Tensor         # [2I, D]  rows interleaved gate/up
-    down_w: torch.Tensor       # [D, I]
+    gu_w: torch.Tensor         # packed [2I, D]  rows interleaved gate/up
+    down_w: torch.Tensor       # packed [D, I]
 
 
 @dataclass
@@ -255,49 +280,75 @@ class VLAWeights:
     fc1_w: torch.Tensor; fc1_b: torch.Tensor
     fc2_w: torch.Tensor; fc2_b: torch.Tensor
     fc3_w: torch.Tensor; fc3_b: torch.Tensor
-    embed: torch.Tensor
+    embed: torch.Tensor        # row-major [vocab, D] (gathered, never a GEMM operand)
     layers: List[LayerW]
     norm: torch.Tensor
-    lm_head: torch.Tensor
+    lm_head: torch.Tensor      # packed
     placements: Dict[str, Placement] = field(default_factory=dict)
+    groups: List[PackedGroup] = field(default_factory=list)
+
+    def _specs(self) -> Dict[str, TensorSpec]:
+        return {s.name: s for s in tensor_specs(self.dims)}
 
     # ---- filling ----
     def fill_synthetic(self, seed: int = 0) -> "VLAWeights":
-        """Fill every tensor on the device with the deterministic generator (bl_fill_synth_bf16_2d); the CPU oracle
-        builds the identical tensors from the same (name, seed, mean, std) with oracle/synth.py."""
+        """Fill every tensor on the device with the deterministic generator (bl_fill_synth_bf16_2d), then pack the GEMM
+        weights (bl_pack_weight_bf16); the CPU oracle builds the identical tensors from the same (name, seed, mean,
+        std) with oracle/synth.py."""
         from . import ops
-        for spec in tensor_specs(self.dims):
-            pl = self.placements[spec.name]
-            flat = pl.dst.view(-1)[pl.offset:]
-            ops.fill_synth(flat, tensor_seed(spec.name, seed), spec.mean, spec.std / IRWIN_HALL_SD,
+        specs = self._specs()
+
+        def fill(flat, name):
+            spec, pl = specs[name], self.placements[name]
+            ops.fill_synth(flat[pl.offset:], tensor_seed(name, seed), spec.mean, spec.std / IRWIN_HALL_SD,
                            rows=pl.rows, cols=pl.cols, ld=pl.ld)
+        for name, pl in self.placements.items():
+            if pl.group is None:
+                fill(pl.dst.view(-1), name)
+        for g in self.groups:
+            staging = torch.zeros(g.n, g.k, dtype=torch.bfloat16, device=g.packed.device)
+            for name in g.members:
+                fill(staging.view(-1), name)
+            _pack(staging, g.packed)
         return self
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> "VLAWeights":
         """Pack an HF-named state dict (bf16/fp32 tensors on any device) into the device layout."""
-        missing = []
-        for spec in tensor_specs(self.dims):
-            if spec.name not in sd:
-                missing.append(spec.name)
-                continue
-            src = sd[spec.name]
-            if tuple(src.shape) != spec.shape:
-                raise ValueError(f"{spec.name}: expected {spec.shape}, got {tuple(src.shape)}")
-            pl = self.placements[spec.name]
-            dst = _block_view(pl)
-            dst.copy_(src.reshape(pl.rows, pl.cols).to(device=dst.device, dtype=torch.bfloat16))
+        specs = self._specs()
+        missing = [n for n in specs if n not in sd]
         if strict and missing:
             raise KeyError(f"state dict is missing {len(missing)} tensors, e.g. {missing[:3]}")
+
+        def put(flat, name):
+            spec, pl = specs[name], self.placements[name]
+            src = sd[name]
+            if tuple(src.shape) != spec.shape:
+                raise ValueError(f"{name}: expected {spec.shape}, got {tuple(src.shape)}")
+            _block_view(flat, pl).copy_(src.reshape(pl.rows, pl.cols).to(device=flat.device, dtype=torch.bfloat16))
+        for name, pl in self.placements.items():
+            if pl.group is None and name in sd:
+                put(pl.dst.view(-1), name)
+        for g in self.groups:
+            if not all(n in sd for n in g.members):
+                continue
+            staging = torch.zeros(g.n, g.k, dtype=torch.bfloat16, device=g.packed.device)
+            for name in g.members:
+                put(staging.view(-1), name)
+            _pack(staging, g.packed)
         return self
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         """Unpack to HF names/shapes (device tensors, copies)."""
+        specs = self._specs()
         out = {}
-        for spec in tensor_specs(self.dims):
-            pl = self.placements[spec.name]
-            src = _block_view(pl)
-            out[spec.name] = src.clone().reshape(spec.shape)
-        return out
+        for name, pl in self.placements.items():
+            if pl.group is None:
+                out[name] = _block_view(pl.dst.view(-1), pl).clone().reshape(specs[name].shape)
+        for g in self.groups:
+            staging = _unpack(g.packed).contiguous()
+            for name in g.members:
+                out[name] = _block_view(staging.view(-1), self.placements[name]).clone().reshape(specs[name].shape)
+        return {n: out[n] for n in specs}
 
 
 def allocate(dims: VLADims, device: torch.device | str = "cuda") -> VLAWeights:
@@ -305,77 +356,75 @@ def allocate(dims: VLADims, device: torch.device | str = "cuda") -> VLAWeights:
     device = torch.device(device)
     arena = Arena(device)
     pending: List[Tuple[int, Callable[[torch.Tensor], None]]] = []
-    placements: Dict[str, Placement] = {}
+    plain: Dict[str, tuple] = {}                 # name → (holder, key, offset, rows, cols, ld)
+    grouped: Dict[str, tuple] = {}               # name → (group id, offset, rows, cols, ld)
+    group_defs: List[tuple] = []                 # (holder, key, n, k)
 
-    def T(shape, setter):
-        pending.append((arena.reserve(tuple(shape)), setter))
+    def dense(holder, key, shape):
+        pending.append((arena.reserve(tuple(shape)), lambda x, h=holder, k=key: h.__setitem__(k, x)))
 
-    def place(name, holder, key, offset, rows, cols, ld):
-        placements[name] = (holder, key, offset, rows, cols, ld)   # resolved after commit
-
-    holders: Dict[str, dict] = {}
+    def gemm_w(holder, key, n, k) -> int:
+        assert n % 16 == 0 and k % 64 == 0, (key, n, k)
+        pending.append((arena.reserve((n // 16, k // 32, 64, 8)), lambda x, h=holder, kk=key: h.__setitem__(kk, x)))
+        group_defs.append((holder, key, n, k))
+        return len(group_defs) - 1
 
     def tower(t: TowerDims) -> dict:
         h = {"blocks": [dict() for _ in range(t.n_run)]}
-        p, D, Hp = t.prefix, t.dim, t.mlp_pad
-        kp = _pad64(dims.patch_k)
-        T((D, kp), lambda x: h.__setitem__("patch_w", x)); place(f"{p}.patch_embed.proj.weight", h, "patch_w", 0, D, dims.patch_k, kp)
-        T((D,), lambda x: h.__setitem__("patch_b", x)); place(f"{p}.patch_embed.proj.bias", h, "patch_b", 0, 1, D, D)
-        T((256, D), lambda x: h.__setitem__("pos", x)); place(f"{p}.pos_embed", h, "pos", 0, 256, D, D)
+        p, D, Hp, kp = t.prefix, t.dim, t.mlp_pad, _pad64(dims.patch_k)
+        g = gemm_w(h, "patch_w", D, kp); grouped[f"{p}.patch_embed.proj.weight"] = (g, 0, D, dims.patch_k, kp)
+        dense(h, "patch_b", (D,)); plain[f"{p}.patch_embed.proj.bias"] = (h, "patch_b", 0, 1, D, D)
+        dense(h, "pos", (256, D)); plain[f"{p}.pos_embed"] = (h, "pos", 0, 256, D, D)
         if t.n_prefix:
-            T((t.n_prefix, D), lambda x: h.__setitem__("prefix", x))
-            place(f"{p}.cls_token", h, "prefix", 0, 1, D, D)
-            place(f"{p}.reg_token", h, "prefix", D, t.n_prefix - 1, D, D)
+            dense(h, "prefix", (t.n_prefix, D))
+            plain[f"{p}.cls_token"] = (h, "prefix", 0, 1, D, D)
+            plain[f"{p}.reg_token"] = (h, "prefix", D, t.n_prefix - 1, D, D)
         else:
             h["prefix"] = None
         for i in range(t.n_run):
             b, bn = h["blocks"][i], f"{p}.blocks.{i}"
-
-            def reg(key, shape, hf, rows, cols, ld, b=b):
-                T(shape, lambda x, b=b, key=key: b.__setitem__(key, x))
-                place(hf, b, key, 0, rows, cols, ld)
-            reg("norm1_w", (D,), f"{bn}.norm1.weight", 1, D, D); reg("norm1_b", (D,), f"{bn}.norm1.bias", 1, D, D)
-            reg("qkv_w", (3 * D, D), f"{bn}.attn.qkv.weight", 3 * D, D, D); reg("qkv_b", (3 * D,), f"{bn}.attn.qkv.bias", 1, 3 * D, 3 * D)
-            reg("proj_w", (D, D), f"{bn}.attn.proj.weight", D, D, D); reg("proj_b", (D,), f"{bn}.attn.proj.bias", 1, D, D)
-            reg("norm2_w", (D,), f"{bn}.norm2.weight", 1, D, D); reg("norm2_b", (D,), f"{bn}.norm2.bias", 1, D, D)
-            reg("fc1_w", (Hp, D), f"{bn}.mlp.fc1.weight", t.mlp, D, D); reg("fc1_b", (Hp,), f"{bn}.mlp.fc1.bias", 1, t.mlp, t.mlp)
-            reg("fc2_w", (D, Hp), f"{bn}.mlp.fc2.weight", D, t.mlp, Hp); reg("fc2_b", (D,), f"{bn}.mlp.fc2.bias", 1, D, D)
+            for key, hf in (("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"), ("norm2_w", "norm2.weight"),
+                            ("norm2_b", "norm2.bias"), ("proj_b", "attn.proj.bias"), ("fc2_b", "mlp.fc2.bias")):
+                dense(b, key, (D,)); plain[f"{bn}.{hf}"] = (b, key, 0, 1, D, D)
+            dense(b, "qkv_b", (3 * D,)); plain[f"{bn}.attn.qkv.bias"] = (b, "qkv_b", 0, 1, 3 * D, 3 * D)
+            dense(b, "fc1_b", (Hp,)); plain[f"{bn}.mlp.fc1.bias"] = (b, "fc1_b", 0, 1, t.mlp, t.mlp)
+            g = gemm_w(b, "qkv_w", 3 * D, D); grouped[f"{bn}.attn.qkv.weight"] = (g, 0, 3 * D, D, D)
+            g = gemm_w(b, "proj_w", D, D); grouped[f"{bn}.attn.proj.weight"] = (g, 0, D, D, D)
+            g = gemm_w(b, "fc1_w", Hp, D); grouped[f"{bn}.mlp.fc1.weight"] = (g, 0, t.mlp, D, D)
+            g = gemm_w(b, "fc2_w", D, Hp); grouped[f"{bn}.mlp.fc2.weight"] = (g, 0, D, t.mlp, Hp)
             if t.layerscale:
-                reg("ls1", (D,), f"{bn}.ls1.scale_factor", 1, D, D); reg("ls2", (D,), f"{bn}.ls2.scale_factor", 1, D, D)
+                dense(b, "ls1", (D,)); plain[f"{bn}.ls1.scale_factor"] = (b, "ls1", 0, 1, D, D)
+                dense(b, "ls2", (D,)); plain[f"{bn}.ls2.scale_factor"] = (b, "ls2", 0, 1, D, D)
             else:
                 b["ls1"] = b["ls2"] = None
         return h
 
-    holders["dino"], holders["siglip"] = tower(dims.dino), tower(dims.siglip)
+    hd, hs = tower(dims.dino), tower(dims.siglip)
     top: dict = {}
     V, P, L, I = dims.vision_dim, 4 * dims.vision_dim, dims.llm_dim, dims.llm_inter
-
-    def reg_top(key, shape, hf, rows, cols, ld):
-        T(shape, lambda x, key=key: top.__setitem__(key, x))
-        place(hf, top, key, 0, rows, cols, ld)
-    reg_top("fc1_w", (P, V), "projector.fc1.weight", P, V, V); reg_top("fc1_b", (P,), "projector.fc1.bias", 1, P, P)
-    reg_top("fc2_w", (L, P), "projector.fc2.weight", L, P, P); reg_top("fc2_b", (L,), "projector.fc2.bias", 1, L, L)
-    reg_top("fc3_w", (L, L), "projector.fc3.weight", L, L, L); reg_top("fc3_b", (L,), "projector.fc3.bias", 1, L, L)
+    for key, hf, n, k in (("fc1_w", "projector.fc1.weight", P, V), ("fc2_w", "projector.fc2.weight", L, P),
+                          ("fc3_w", "projector.fc3.weight", L, L)):
+        g = gemm_w(top, key, n, k); grouped[hf] = (g, 0, n, k, k)
+    for key, hf, n in (("fc1_b", "projector.fc1.bias", P), ("fc2_b", "projector.fc2.bias", L),
+                       ("fc3_b", "projector.fc3.bias", L)):
+        dense(top, key, (n,)); plain[hf] = (top, key, 0, 1, n, n)
     lm = "language_model.model"
-    reg_top("embed", (dims.vocab, L), f"{lm}.embed_tokens.weight", dims.vocab, L, L)
+    dense(top, "embed", (dims.vocab, L)); plain[f"{lm}.embed_tokens.weight"] = (top, "embed", 0, dims.vocab, L, L)
     layer_h = [dict() for _ in range(dims.llm_layers)]
     for i, lh in enumerate(layer_h):
         bn = f"{lm}.layers.{i}"
-
-        def regl(key, shape, lh=lh):
-            T(shape, lambda x, lh=lh, key=key: lh.__setitem__(key, x))
-        regl("ln1", (L,)); place(f"{bn}.input_layernorm.weight", lh, "ln1", 0, 1, L, L)
-        regl("qkv_w", (3 * L, L))
+        dense(lh, "ln1", (L,)); plain[f"{bn}.input_layernorm.weight"] = (lh, "ln1", 0, 1, L, L)
+        dense(lh, "ln2", (L,)); plain[f"{bn}.post_attention_layernorm.weight"] = (lh, "ln2", 0, 1, L, L)
+        g = gemm_w(lh, "qkv_w", 3 * L, L)
         for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
-            place(f"{bn}.self_attn.{n}.weight", lh, "qkv_w", j * L * L, L, L, L)
-        regl("o_w", (L, L)); place(f"{bn}.self_attn.o_proj.weight", lh, "o_w", 0, L, L, L)
-        regl("ln2", (L,)); place(f"{bn}.post_attention_layernorm.weight", lh, "ln2", 0, 1, L, L)
-        regl("gu_w", (2 * I, L))
-        place(f"{bn}.mlp.gate_proj.weight", lh, "gu_w", 0, I, L, 2 * L)
-        place(f"{bn}.mlp.up_proj.weight", lh, "gu_w", L, I, L, 2 * L)
-        regl("down_w", (L, I)); place(f"{bn}.mlp.down_proj.weight", lh, "down_w", 0, L, I, I)
-    reg_top("norm", (L,), f"{lm}.norm.weight", 1, L, L)
-    reg_top("lm_head", (dims.vocab, L), "language_model.lm_head.weight", dims.vocab, L, L)
+            grouped[f"{bn}.self_attn.{n}.weight"] = (g, j * L * L, L, L, L)
+        g = gemm_w(lh, "o_w", L, L); grouped[f"{bn}.self_attn.o_proj.weight"] = (g, 0, L, L, L)
+        g = gemm_w(lh, "gu_w", 2 * I, L)
+        grouped[f"{bn}.mlp.gate_proj.weight"] = (g, 0, I, L, 2 * L)      # row 2j   = gate_j
+        grouped[f"{bn}.mlp.up_proj.weight"] = (g, L, I, L, 2 * L)        # row 2j+1 = up_j
+        g = gemm_w(lh, "down_w", L, I); grouped[f"{bn}.mlp.down_proj.weight"] = (g, 0, L, I, I)
+    dense(top, "norm", (L,)); plain[f"{lm}.norm.weight"] = (top, "norm", 0, 1, L, L)
+    g = gemm_w(top, "lm_head", dims.vocab, L); grouped["language_model.lm_head.weight"] = (g, 0, dims.vocab, L, L)
 
     arena.commit()
     for idx, setter in pending:
@@ -384,9 +433,13 @@ def allocate(dims: VLADims, device: torch.device | str = "cuda") -> VLAWeights:
     def mk_tower(t: TowerDims, h: dict) -> TowerW:
         return TowerW(t, h["patch_w"], h["patch_b"], h["pos"], h["prefix"], [BlockW(**b) for b in h["blocks"]])
 
-    w = VLAWeights(dims, arena, mk_tower(dims.dino, holders["dino"]), mk_tower(dims.siglip, holders["siglip"]),
+    w = VLAWeights(dims, arena, mk_tower(dims.dino, hd), mk_tower(dims.siglip, hs),
                    top["fc1_w"], top["fc1_b"], top["fc2_w"], top["fc2_b"], top["fc3_w"], top["fc3_b"], top["embed"],
                    [LayerW(**lh) for lh in layer_h], top["norm"], top["lm_head"])
-    w.placements = {name: Placement(holder[key], off, rows, cols, ld)
-                    for name, (holder, key, off, rows, cols, ld) in placements.items()}
+    w.groups = [PackedGroup(holder[key], n, k) for holder, key, n, k in group_defs]
+    for name, (holder, key, off, rows, cols, ld) in plain.items():
+        w.placements[name] = Placement(holder[key], off, rows, cols, ld)
+    for name, (gi, off, rows, cols, ld) in grouped.items():
+        w.placements[name] = Placement(None, off, rows, cols, ld, w.groups[gi])
+        w.groups[gi].members.append(name)
     return w

@@ -45,6 +45,13 @@ int bl_fill_synth_bf16(bl_bf16* dst, int64_t n, uint32_t seed, float mean, float
 int bl_fill_synth_bf16_2d(bl_bf16* dst, int64_t rows, int64_t cols, int64_t ld, uint32_t seed, float mean,
                           float scale, void* stream);
 
+/* ---- weight layout ------------------------------------------------------------------------------------------------- */
+/* Every GEMM weight lives in HBM in MFMA-fragment-major order: packed[nt][ks][lane][8] (nt = n/16, ks = k/32) holds
+ * W[16*nt + (lane & 15)][32*ks + 8*(lane >> 4) .. +7] — the 16 bytes lane `lane` feeds v_mfma_f32_16x16x32_bf16. Each
+ * (nt, ks) block is one contiguous KiB. bl_pack_weight_bf16 converts an nn.Linear-layout matrix src[n, k] (leading
+ * dimension ld) once at load time; n % 16 == 0, k % 32 == 0 (pad with zeros first). */
+int bl_pack_weight_bf16(const bl_bf16* src, int64_t ld, int64_t n, int64_t k, bl_bf16* dst, void* stream);
+
 /* ---- GEMM: C[M,N] = epilogue(A[M,K] * W[N,K]^T) ------------------------------------------------------------- */
 /* Replaces every nn.Linear on the path: timm Attention.qkv/proj + Mlp.fc1/fc2 (created at
  * modeling_prismatic.py:78-101), PrismaticProjector fc1/fc2/fc3 (modeling_prismatic.py:146-158), and the HF Llama
@@ -63,7 +70,7 @@ enum bl_epilogue {
 
 typedef struct bl_gemm_desc {
   const bl_bf16* A;  int64_t lda;      /* [M, K] activations                                                  */
-  const bl_bf16* W;  int64_t ldw;      /* [N, K] weights (nn.Linear layout)                                   */
+  const bl_bf16* W;  int64_t ldw;      /* [N, K] weights, fragment-major (bl_pack_weight_bf16); ldw must equal K */
   void* C;           int64_t ldc;      /* [M, N] (or [M, N/2] for SWIGLU); bf16, or fp32 for BL_EPI_F32*      */
   int32_t M, N, K;                     /* K % 64 == 0 (pad in HBM), N % 16 == 0                               */
   int32_t epilogue;                    /* enum bl_epilogue                                                    */

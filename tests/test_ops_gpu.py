@@ -22,6 +22,12 @@ def dv(x, dev):
     return x.to(torch.bfloat16).to(dev)
 
 
+def pk(w, dev):
+    """nn.Linear-layout CPU weight → packed (fragment-major) device weight."""
+    from bridgelang_amd import ops
+    return ops.pack_weight(dv(w, dev))
+
+
 def close_bf16(got, ref, what, rtol=2 ** -6, atol_scale=2 ** -8, min_exact=0.98):
     got = got.float().cpu()
     ref = ref.float()
@@ -66,15 +72,27 @@ def test_fill_synth_padded_and_interleaved(dev):
     assert torch.equal(gu.cpu()[0::2], g) and torch.equal(gu.cpu()[1::2], u)
 
 
+def test_pack_weight(dev):
+    from bridgelang_amd import ops
+    w = rand_bf16((4304 // 16 * 16, 1088), 3)
+    got = ops.pack_weight(dv(w, dev)).cpu().float()
+    n, k = w.shape
+    ref = w.view(n // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(n // 16, k // 32, 64, 8)
+    assert torch.equal(got, ref)
+    assert torch.equal(ops.unpack_weight(ops.pack_weight(dv(w, dev))).cpu().float(), w)
+
+
 # ---- tiled GEMM -----------------------------------------------------------------------------------------------------
-GEMM_SHAPES = [(300, 192, 128), (128, 128, 64), (261 * 2, 1152, 576), (77, 4304 // 16 * 16, 256), (1, 64, 64)]
+# the last three are large enough for the 256x256 pipelined kernel (ragged M and N, odd and even K-tile counts)
+GEMM_SHAPES = [(300, 192, 128), (128, 128, 64), (261 * 2, 1152, 576), (77, 4304 // 16 * 16, 256), (1, 64, 64),
+               (1044, 528, 320), (2304, 1024, 512), (1100, 4304 // 16 * 16, 1152)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_none_bias_gelu(dev, M, N, K):
     from bridgelang_amd import ops
     a, w, b = rand_bf16((M, K), 1), rand_bf16((N, K), 2, 0.05), rand_bf16((N,), 3, 0.1)
-    A, W, Bv = dv(a, dev), dv(w, dev), dv(b, dev)
+    A, W, Bv = dv(a, dev), pk(w, dev), dv(b, dev)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     ops.gemm(A, W, out, ops.EPI_NONE, skinny=False)
     close_bf16(out, R.linear(P, a, w), "EPI_NONE")
@@ -90,12 +108,13 @@ def test_gemm_none_bias_gelu(dev, M, N, K):
     close_bf16(outf, R.linear(P, a, w), "EPI_F32_BF16R")
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 192, 128), (522, 256, 1088)])
+@pytest.mark.parametrize("M,N,K", [(300, 192, 128), (522, 256, 1088), (1305, 768, 448)])
 def test_gemm_residual_layerscale_swiglu(dev, M, N, K):
     from bridgelang_amd import ops
     a, w, b = rand_bf16((M, K), 1), rand_bf16((N, K), 2, 0.05), rand_bf16((N,), 3, 0.1)
     r, ls = rand_bf16((M, N), 4), rand_bf16((N,), 5, 0.3)
-    A, W, Bv, Rr, Ls = (dv(t, dev) for t in (a, w, b, r, ls))
+    A, Bv, Rr, Ls = (dv(t, dev) for t in (a, b, r, ls))
+    W = pk(w, dev)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     ops.gemm(A, W, out, ops.EPI_RES, res=Rr, skinny=False)
     close_bf16(out, P.rb(r + R.linear(P, a, w)), "EPI_RES")
@@ -112,7 +131,7 @@ def test_gemm_residual_layerscale_swiglu(dev, M, N, K):
     gate, up = w[:I], w[I:]
     gu = torch.stack([gate, up], 1).reshape(N, K)
     out2 = torch.empty(M, I, dtype=torch.bfloat16, device=dev)
-    ops.gemm(A, dv(gu, dev), out2, ops.EPI_SWIGLU, skinny=False)
+    ops.gemm(A, pk(gu, dev), out2, ops.EPI_SWIGLU, skinny=False)
     g, u = R.linear(P, a, gate), R.linear(P, a, up)
     close_bf16(out2, P.rb(P.rb(torch.nn.functional.silu(g)) * u), "EPI_SWIGLU")
 
@@ -123,7 +142,7 @@ def test_gemm_row_remap_and_table_residual(dev):
     B, D, K = 2, 128, 640
     a, w, b, pos = rand_bf16((B * 256, K), 1), rand_bf16((D, K), 2, 0.05), rand_bf16((D,), 3, 0.1), rand_bf16((256, D), 4)
     out = torch.full((B * 261, D), 7.0, dtype=torch.bfloat16, device=dev)
-    ops.gemm(dv(a, dev), dv(w, dev), out, ops.EPI_BIAS_RES, bias=dv(b, dev), res=dv(pos, dev), res_row_mod=256,
+    ops.gemm(dv(a, dev), pk(w, dev), out, ops.EPI_BIAS_RES, bias=dv(b, dev), res=dv(pos, dev), res_row_mod=256,
              out_map=(256, 261, 5))
     ref = P.rb(R.linear(P, a, w, b).view(B, 256, D) + pos)
     got = out.cpu().float().view(B, 261, D)
@@ -132,7 +151,7 @@ def test_gemm_row_remap_and_table_residual(dev):
     # tap: input rows [B*261], output only the 256 patch rows per image, into a wider concat buffer
     x = rand_bf16((B * 261, K), 9)
     cat = torch.zeros(B * 256, D + 64, dtype=torch.bfloat16, device=dev)
-    ops.gemm(dv(x, dev), dv(w, dev), cat[:, 64:], ops.EPI_BIAS, bias=dv(b, dev), out_map=(261, 256, -5))
+    ops.gemm(dv(x, dev), pk(w, dev), cat[:, 64:], ops.EPI_BIAS, bias=dv(b, dev), out_map=(261, 256, -5))
     ref2 = R.linear(P, x, w, b).view(B, 261, D)[:, 5:].reshape(B * 256, D)
     close_bf16(cat[:, 64:], ref2, "tap remap")
     assert (cat[:, :64] == 0).all()
@@ -143,7 +162,7 @@ def test_gemm_row_remap_and_table_residual(dev):
 def test_gemm_skinny(dev, M, N, K):
     from bridgelang_amd import ops
     a, w, r = rand_bf16((M, K), 1), rand_bf16((N, K), 2, 0.05), rand_bf16((M, N), 4)
-    A, W, Rr = dv(a, dev), dv(w, dev), dv(r, dev)
+    A, W, Rr = dv(a, dev), pk(w, dev), dv(r, dev)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     ops.gemm(A, W, out, ops.EPI_NONE, skinny=True)
     close_bf16(out, R.linear(P, a, w), "skinny NONE")
@@ -152,7 +171,7 @@ def test_gemm_skinny(dev, M, N, K):
     I = N // 2
     gu = torch.stack([w[:I], w[I:]], 1).reshape(N, K)
     out2 = torch.empty(M, I, dtype=torch.bfloat16, device=dev)
-    ops.gemm(A, dv(gu, dev), out2, ops.EPI_SWIGLU, skinny=True)
+    ops.gemm(A, pk(gu, dev), out2, ops.EPI_SWIGLU, skinny=True)
     g, u = R.linear(P, a, w[:I]), R.linear(P, a, w[I:])
     close_bf16(out2, P.rb(P.rb(torch.nn.functional.silu(g)) * u), "skinny SWIGLU")
     outf = torch.empty(M, N, dtype=torch.float32, device=dev)
