@@ -160,17 +160,13 @@ def cpu_baseline(dims, B: int, L: int) -> dict:
 
 def main() -> None:
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from bridgelang_amd import replicas
+    rank, local, world = replicas.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    distributed = replicas.init("nccl", dev)      # RCCL; only the timing fence uses it (replicas, no data-path collective)
 
     from bridgelang_amd import weights as W
     from bridgelang_amd.engine import OpenVLAEngine
@@ -186,22 +182,12 @@ def main() -> None:
     for _ in range(args.warmup):
         eng.replay()
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
+    replicas.fence(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.replay()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    replicas.fence(dev)
+    elapsed = replicas.max_over_ranks(time.perf_counter() - t0, dev)
     ids_out = eng.gen_ids.t().cpu()
 
     if rank == 0:
@@ -224,7 +210,7 @@ def main() -> None:
                        "replicas": world, "hip_graph": not args.no_graph},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "gemm_nt_kernel (bl_gemm_bf16)", "launches_per_step": gemm["launches"],
+                         "kernel": "gemm256_kernel + gemm128_kernel tail (per bl_gemm_bf16 call)", "launches_per_step": gemm["launches"],
                          "avg_launch_us": round(gemm["ms"] * 1e3 / gemm["launches"], 2),
                          "algorithmic_gflop_per_launch": round(gemm["flops"] / gemm["launches"] / 1e9, 3)},
             "end_to_end": {"algorithmic_tflop_per_seq": ALGO_TFLOP_PER_SEQ,
@@ -235,14 +221,12 @@ def main() -> None:
                            "decode_hbm_frac": (round(skinny["bytes"] / (skinny["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if skinny else None),
                            "first_ids": ids_out[0].tolist()},
         }
-        if not args.no_cpu_baseline and args.model == "openvla-7b":
-            line["cpu_baseline"] = cpu_baseline(dims, args.batch, args.prompt_len)
-        elif not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dims, args.batch, args.prompt_len)
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if distributed:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
