@@ -33,6 +33,10 @@ class GemmDesc(C.Structure):
         ("res", C.c_void_p), ("ldres", C.c_int64),
         ("res_row_mod", C.c_int32),
         ("out_group", C.c_int32), ("out_stride", C.c_int32), ("out_offset", C.c_int32),
+        ("a_norm_weight", C.c_void_p),
+        ("a_norm_eps", C.c_float),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -65,6 +69,7 @@ SIGNATURES = {
     "bl_rmsnorm_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "bl_attention_bf16": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "bl_attention_decode_bf16": (C.c_int, [C.POINTER(AttnDesc), _vp]),
+    "bl_attention_decode_rope_bf16": (C.c_int, [C.POINTER(AttnDesc), _vp, _vp, _i32, _vp]),
     "bl_rope_kvcache_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "bl_embed_splice_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "bl_argmax_f32": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),

@@ -187,7 +187,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 // lane&15), so one wave-instruction reads 4 whole 256-byte rows; the 4 waves interleave 16-key groups, and every
 // wave keeps 4 independent row loads in flight. Scores go through LDS once; the softmax statistics are recomputed by
 // every wave (Skv ≤ 2048 floats), the PV partials of the 4 waves are summed through LDS.
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
+// ROPE = true additionally rotates q and the new token's k at position `pos`, appends k', v to cache row `pos`
+// and treats that row as the last key (HF apply_rotary_pos_emb + DynamicCache.update, fused).
+template <bool ROPE>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p, const uint16_t* kn, const uint16_t* vn,
+                                                          const uint16_t* cos_tab, const uint16_t* sin_tab, int pos) {
   constexpr int MAXKV = 2048;   // head_dim is fixed at 128 (16 lanes × 16 B per row)
   __shared__ float sc[MAXKV];
   __shared__ float part[4][128];
@@ -195,26 +199,51 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
   const int bh = blockIdx.x;
   const int b = bh / p.H, h = bh - b * p.H;
   const int ks = lane >> 4, dc = lane & 15;
+  const long qoff = (long)b * p.q_bs + (long)h * p.q_hs;
+  const uint8_t* mrow = p.mask ? p.mask + (long)b * p.mask_bs : nullptr;
+  const int n = p.Skv, n_cache = ROPE ? n - 1 : n;
+  uint16_t* kc = const_cast<uint16_t*>(p.k) + (long)b * p.k_bs + (long)h * p.k_hs + dc * 8;
+  uint16_t* vc = const_cast<uint16_t*>(p.v) + (long)b * p.v_bs + (long)h * p.v_hs + dc * 8;
 
   float qv[8];
-  {
-    const u32x4_t t = *(const u32x4_t*)(p.q + (long)b * p.q_bs + (long)h * p.q_hs + dc * 8);
+  float knv[8], vnv[8];   // ROPE: rotated new key / new value chunk (bf16 values)
+  if constexpr (ROPE) {
+    // half-split rotation: chunk dc pairs with chunk dc ^ 8; out = bf16(bf16(own*cos) + bf16(±partner*sin))
+    const u32x4_t cq = *(const u32x4_t*)(cos_tab + (long)pos * 64 + (dc & 7) * 8);
+    const u32x4_t sq = *(const u32x4_t*)(sin_tab + (long)pos * 64 + (dc & 7) * 8);
+    const float sgn = dc < 8 ? -1.f : 1.f;
+    const u32x4_t q_own = *(const u32x4_t*)(p.q + qoff + dc * 8), q_par = *(const u32x4_t*)(p.q + qoff + (dc ^ 8) * 8);
+    const u32x4_t k_own = *(const u32x4_t*)(kn + qoff + dc * 8), k_par = *(const u32x4_t*)(kn + qoff + (dc ^ 8) * 8);
+    const u32x4_t v_own = *(const u32x4_t*)(vn + qoff + dc * 8);
+    u32x4_t kw;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float c0 = bflo(cq[i]), c1 = bfhi(cq[i]), s0 = bflo(sq[i]) * sgn, s1 = bfhi(sq[i]) * sgn;
+      qv[2 * i] = rbf(rbf(bflo(q_own[i]) * c0) + rbf(bflo(q_par[i]) * s0));
+      qv[2 * i + 1] = rbf(rbf(bfhi(q_own[i]) * c1) + rbf(bfhi(q_par[i]) * s1));
+      knv[2 * i] = rbf(rbf(bflo(k_own[i]) * c0) + rbf(bflo(k_par[i]) * s0));
+      knv[2 * i + 1] = rbf(rbf(bfhi(k_own[i]) * c1) + rbf(bfhi(k_par[i]) * s1));
+      vnv[2 * i] = bflo(v_own[i]); vnv[2 * i + 1] = bfhi(v_own[i]);
+      kw[i] = pack2bf(knv[2 * i], knv[2 * i + 1]);
+    }
+    if (wave == 0 && ks == 0) {   // append the new token to the cache (row `pos`)
+      *(u32x4_t*)(kc + (long)pos * p.k_rs) = kw;
+      *(u32x4_t*)(vc + (long)pos * p.v_rs) = v_own;
+    }
+  } else {
+    const u32x4_t t = *(const u32x4_t*)(p.q + qoff + dc * 8);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { qv[2 * i] = bflo(t[i]); qv[2 * i + 1] = bfhi(t[i]); }
   }
-  const uint16_t* kbase = p.k + (long)b * p.k_bs + (long)h * p.k_hs + dc * 8;
-  const uint16_t* vbase = p.v + (long)b * p.v_bs + (long)h * p.v_hs + dc * 8;
-  const uint8_t* mrow = p.mask ? p.mask + (long)b * p.mask_bs : nullptr;
-  const int n = p.Skv;
 
   // ---- scores: groups of 64 keys per workgroup iteration; wave w takes keys g*64 + w*16 + j*4 + ks, j = 0..3 ----
-  for (int g0 = 0; g0 < n; g0 += 64) {
+  for (int g0 = 0; g0 < n_cache; g0 += 64) {
     u32x4_t kq[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int key = g0 + wave * 16 + j * 4 + ks;
       kq[j] = (u32x4_t){0u, 0u, 0u, 0u};
-      if (key < n) kq[j] = *(const u32x4_t*)(kbase + (long)key * p.k_rs);
+      if (key < n_cache) kq[j] = *(const u32x4_t*)(kc + (long)key * p.k_rs);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -223,8 +252,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) d += qv[2 * i] * bflo(kq[j][i]) + qv[2 * i + 1] * bfhi(kq[j][i]);
       d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
-      if (dc == 0 && key < n) sc[key] = (mrow && mrow[key] == 0) ? -INFINITY : d * p.scale_log2e;
+      if (dc == 0 && key < n_cache) sc[key] = (mrow && mrow[key] == 0) ? -INFINITY : d * p.scale_log2e;
     }
+  }
+  if constexpr (ROPE) {   // score of the new key, from registers
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d += qv[i] * knv[i];
+    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+    if (wave == 0 && lane == 0) sc[pos] = (mrow && mrow[pos] == 0) ? -INFINITY : d * p.scale_log2e;
   }
   __syncthreads();
   // ---- softmax statistics (every wave, redundantly; identical results) ----
@@ -238,7 +274,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
 
   // ---- PV: same key assignment; P rounded to bf16 as in the prefill kernel ----
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int g0 = 0; g0 < n; g0 += 64) {
+  for (int g0 = 0; g0 < n_cache; g0 += 64) {
     u32x4_t vq[4];
     float pk[4];
 #pragma unroll
@@ -246,8 +282,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
       const int key = g0 + wave * 16 + j * 4 + ks;
       vq[j] = (u32x4_t){0u, 0u, 0u, 0u};
       pk[j] = 0.f;
-      if (key < n) {
-        vq[j] = *(const u32x4_t*)(vbase + (long)key * p.v_rs);
+      if (key < n_cache) {
+        vq[j] = *(const u32x4_t*)(vc + (long)key * p.v_rs);
         pk[j] = rbf(__builtin_amdgcn_exp2f(sc[key] - m_use));
       }
     }
@@ -255,6 +291,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) { acc[2 * i] += pk[j] * bflo(vq[j][i]); acc[2 * i + 1] += pk[j] * bfhi(vq[j][i]); }
+  }
+  if constexpr (ROPE) {
+    if (wave == 0 && ks == 0) {
+      const float pn = rbf(__builtin_amdgcn_exp2f(sc[pos] - m_use));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += pn * vnv[i];
+    }
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) { acc[i] += __shfl_xor(acc[i], 16, 64); acc[i] += __shfl_xor(acc[i], 32, 64); }
@@ -318,7 +361,23 @@ extern "C" int bl_attention_decode_bf16(const bl_attn_desc* d, void* stream) {
   if (rc != BL_OK) return rc;
   if (d->head_dim != 128 || d->Sq != 1 || d->Skv > 2048) return BL_E_SHAPE;
   if (((uintptr_t)d->o) & 15) return BL_E_ALIGN;
-  hipLaunchKernelGGL(attn_decode_kernel, dim3(d->B * d->H), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((attn_decode_kernel<false>), dim3(d->B * d->H), dim3(256), 0, (hipStream_t)stream, a,
+                     (const uint16_t*)nullptr, (const uint16_t*)nullptr, (const uint16_t*)nullptr, (const uint16_t*)nullptr, 0);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_attention_decode_rope_bf16(const bl_attn_desc* d, const bl_bf16* cos_tab, const bl_bf16* sin_tab,
+                                             int32_t pos, void* stream) {
+  AttnArgs a;
+  const int rc = fill_args(d, a);
+  if (rc != BL_OK) return rc;
+  if (!cos_tab || !sin_tab) return BL_E_ARG;
+  if (d->head_dim != 128 || d->Sq != 1 || d->Skv > 2048 || pos < 0 || d->Skv != pos + 1) return BL_E_SHAPE;
+  if ((((uintptr_t)d->o) & 15) || !bl_aligned16(cos_tab) || !bl_aligned16(sin_tab)) return BL_E_ALIGN;
+  const long D = (long)d->H * d->head_dim;   // q / k_new / v_new are the three thirds of the fused qkv row
+  hipLaunchKernelGGL((attn_decode_kernel<true>), dim3(d->B * d->H), dim3(256), 0, (hipStream_t)stream, a, d->q + D,
+                     d->q + 2 * D, cos_tab, sin_tab, pos);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

@@ -159,13 +159,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages × (32 KiB activations + 32 KiB weights)
 
   int tm, tn;
-  tile_coords(p, tm, tn);
+  const int nk_all = p.K / BK;
+  int kt_begin = 0, nk = nk_all;        // this workgroup's K-tile range [kt_begin, nk)
+  if (p.splitk > 1) {                   // split-K tail: blockIdx = leftover tile * splitk + slice; even slice starts
+    lin_to_tile(p, p.tail_base + blockIdx.x / p.splitk, tm, tn);
+    const int slice = blockIdx.x % p.splitk;
+    kt_begin = (int)(((long)slice * nk_all) / p.splitk) & ~1;
+    nk = slice + 1 == p.splitk ? nk_all : ((int)(((long)(slice + 1) * nk_all) / p.splitk) & ~1);
+  } else {
+    tile_coords(p, tm, tn);
+  }
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int l15 = lane & 15, lg = lane >> 4;
-  const int kt32 = p.K >> 5, nk = p.K / BK;
+  const int kt32 = p.K >> 5;
 
   const unsigned a_bytes = (unsigned)min((long)p.M * p.lda * 2, 0xffffffffL);
   const unsigned w_bytes = (unsigned)min((long)p.N * p.K * 2, 0xffffffffL);
@@ -257,15 +266,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
   char* const S1 = smem + STAGE;
 
   // ---- prologue: X0 Y0 Y1 X1 of tile 0 and X0 of tile 1; the first three must have landed ----
-  ISSUE_X(0, 0); ISSUE_Y(0, 0); ISSUE_Y(1, 0); ISSUE_X(1, 0); ISSUE_X(0, 1);
+  ISSUE_X(0, kt_begin); ISSUE_Y(0, kt_begin); ISSUE_Y(1, kt_begin); ISSUE_X(1, kt_begin); ISSUE_X(0, kt_begin + 1);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   READ_X(Xa, 0, S0);
   READ_Y(Ya, 0, S0);
 
-  for (int t = 0; t < nk; t += 2) {
-    // ---- K-tile t (stage 0) ----
+  for (int t = kt_begin; t < nk; t += 2) {
+    // ---- K-tile t (stage 0; kt_begin is even) ----
     ISSUE_Y(0, t + 1); READ_Y(Yb, 1, S0);                    MMA(Xa, Ya, 0, 0); PHASE_END(1);
     ISSUE_Y(1, t + 1); READ_X(Xb, 1, S0);                    MMA(Xa, Yb, 0, 1); PHASE_END(0);
     ISSUE_X(1, t + 1); READ_Y(Ya, 0, S0);                    MMA(Xb, Yb, 1, 1); PHASE_END(1);
@@ -284,12 +293,40 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #undef MMA
 #undef PHASE_END
 
+  if (p.splitk > 1) {   // fp32 partial tile → slab[blockIdx][i*8+j][thread] (16 B per lane, fully coalesced)
+    float* dst = p.slab + ((long)blockIdx.x * 32 * 512 + tid) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *(f32x4_t*)(dst + (long)(i * 8 + j) * 512 * 4) = acc[i][j];
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       epilogue_store4<EPI>(p, m0 + wm * 128 + j * 16 + l15, n0 + wn * 64 + i * 16 + lg * 4, acc[i][j]);
 #endif
+}
+
+// Sum the split-K slabs of the leftover tiles and apply the fused epilogue. Same thread → (m, n) map as gemm256_kernel;
+// grid = leftover tiles × 4, each block handles 8 of the 32 accumulator vectors of a tile.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_splitk_reduce_kernel(GemmArgs p) {
+  int tm, tn;
+  const int tile_local = blockIdx.x >> 2, part = blockIdx.x & 3;
+  lin_to_tile(p, p.tail_base + tile_local, tm, tn);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, l15 = lane & 15, lg = lane >> 4;
+  const int m0 = tm * 256, n0 = tn * 256;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int idx = part * 8 + q, i = idx >> 3, j = idx & 7;
+    f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.splitk; ++s)
+      sum += *(const f32x4_t*)(p.slab + (((long)(tile_local * p.splitk + s) * 32 + idx) * 512 + tid) * 4);
+    epilogue_store4<EPI>(p, m0 + wm * 128 + j * 16 + l15, n0 + wn * 64 + i * 16 + lg * 4, sum);
+  }
 }
 #undef BL_GLDS
 
@@ -328,12 +365,32 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   // time, so its tiles are cut into 128x128 quarters and run by the small kernel (2 workgroups per CU) instead.
   p.tiles_m = bm;
   p.tiles_n = bn;
+  // The last round of 256-tile launches is usually partial (e.g. 288 tiles = 1.125 rounds). Measured cost of the
+  // leftover `tail` tiles in units of one full round T(K) (tools/bench_gemm.py, profiles/): plain partial round 1.0;
+  // 128x128 quarters on the small kernel ≈ 0.65 when they fit one small round (tail ≤ 64 … 128), > 1 beyond; split-K
+  // over S = 256/tail slices ≈ 1/S + 45 µs of fp32 slab traffic, i.e. ≈ 0.28 at K = 11008 but ≈ 0.7 at K = 4096.
   int main_tiles = big_tiles, tail = big_tiles % CUS;
-  if (tail != 0 && tail <= 192 && !force) main_tiles = big_tiles - tail; else tail = 0;
-  hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(main_tiles), dim3(512), LDS256, s, p);
-  if (tail) {
+  const int nk = p.K / BK;
+  int S = tail ? CUS / tail : 1;
+  if (S > 16) S = 16;
+  while (S > 1 && nk / S < 4) --S;
+  static const bool no_split = getenv("BL_GEMM_NO_SPLITK") != nullptr;
+  const bool can_split = tail && S >= 2 && p.K >= 8192 && p.slab &&
+                         p.slab_bytes >= (long)tail * S * 256 * 256 * 4 && !no_split && !force;
+  if (can_split) {
+    main_tiles = big_tiles - tail;
+    if (main_tiles) hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(main_tiles), dim3(512), LDS256, s, p);
     p.tail_base = main_tiles;
-    hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(tail * 4), dim3(256), LDS128, s, p);
+    p.splitk = S;
+    hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(tail * S), dim3(512), LDS256, s, p);
+    hipLaunchKernelGGL((gemm_splitk_reduce_kernel<EPI>), dim3(tail * 4), dim3(512), 0, s, p);
+  } else {
+    if (tail != 0 && tail <= 64 && main_tiles > tail && !force) main_tiles = big_tiles - tail; else tail = 0;
+    hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(main_tiles), dim3(512), LDS256, s, p);
+    if (tail) {
+      p.tail_base = main_tiles;
+      hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(tail * 4), dim3(256), LDS128, s, p);
+    }
   }
   BL_CHECK_LAUNCH();
   return BL_OK;
@@ -346,6 +403,7 @@ extern "C" int bl_gemm_bf16(const bl_gemm_desc* d, void* stream) {
   GemmArgs a;
   const int rc = fill_gemm_args(d, a);
   if (rc != BL_OK) return rc;
+  if (d->a_norm_weight) return BL_E_ARG;   // the fused A-operand RMSNorm exists only in the skinny kernel
   hipStream_t s = (hipStream_t)stream;
   switch (d->epilogue) {
     case BL_EPI_NONE: return launch_gemm<BL_EPI_NONE>(a, s);

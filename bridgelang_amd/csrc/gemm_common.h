@@ -13,6 +13,8 @@ struct GemmArgs {
   int M, N, K;
   int res_row_mod, out_group, out_stride, out_offset;
   int tiles_m, tiles_n;
+  const uint16_t* norm_w; float norm_eps;   // fused RMSNorm on A (skinny kernel)
+  float* slab; long slab_bytes; int splitk;   // split-K tail of the 256x256 kernel (fp32 partial tiles)
   int tail_base;   // >= 0: this launch covers big (256x256) tiles tail_base.. of the tiles_m x tiles_n big-tile grid
 };
 
@@ -88,6 +90,8 @@ inline int fill_gemm_args(const bl_gemm_desc* d, GemmArgs& a) {
   a.res_row_mod = d->res_row_mod; a.out_group = d->out_group; a.out_stride = d->out_stride; a.out_offset = d->out_offset;
   a.tiles_m = a.tiles_n = 0;
   a.tail_base = -1;
+  a.slab = (float*)d->workspace; a.slab_bytes = d->workspace_bytes; a.splitk = 1;
+  a.norm_w = d->a_norm_weight; a.norm_eps = d->a_norm_eps;
   return BL_OK;
 }
 

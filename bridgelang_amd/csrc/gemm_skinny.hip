@@ -23,7 +23,7 @@ constexpr int NW = 8;   // waves per workgroup = K split factor
 
 // KS = MFMA k-steps (32 wide) per wave: K == NW * KS * 32.  GS = k-steps per load group; G = ceil(KS/GS) must be even
 // so the two register buffers alternate with compile-time indices.
-template <int KS, int GS, int EPI>
+template <int KS, int GS, int EPI, bool NORM>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, int n_tiles) {
   constexpr int G = (KS + GS - 1) / GS;
   static_assert(G % 2 == 0, "need an even number of load groups");
@@ -60,7 +60,47 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, int n_
 
   int it = 0;
   int tile = blockIdx.x;
-  if (tile < n_tiles) BL_LOAD_GROUP(0, tile, 0);
+  if (tile < n_tiles) BL_LOAD_GROUP(0, tile, 0);   // first weight group is in flight while the norm prologue runs
+
+  if constexpr (NORM) {
+    // fused HF LlamaRMSNorm on the activation rows: sum of squares over the wave's K-slice, across the 4 lane groups
+    // that share a row, then across the 8 waves through LDS; the fragments are rewritten in registers with the same
+    // two roundings as bl_rmsnorm_bf16.
+    __shared__ float nrm[NW][16];
+    u32x4_t gw[KS];                       // norm weights for this lane's k positions: issued before the reduction
+    {
+      const uint16_t* wn = p.norm_w + kbase;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) gw[s] = *(const u32x4_t*)(wn + s * 32);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const u32x4_t t = __builtin_bit_cast(u32x4_t, xf[s]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ss += bflo(t[i]) * bflo(t[i]) + bfhi(t[i]) * bfhi(t[i]);
+    }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    if (lg == 0) nrm[wave][l15] = ss;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // raw barrier: keep the prefetched weight loads in flight
+    __builtin_amdgcn_s_barrier();
+    float tot = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) tot += nrm[w2][l15];
+    const float rstd = 1.0f / sqrtf(tot * (1.0f / (float)p.K) + p.norm_eps);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const u32x4_t t = __builtin_bit_cast(u32x4_t, xf[s]);
+      const u32x4_t g = gw[s];
+      u32x4_t o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        o[i] = pack2bf(bflo(g[i]) * rbf(bflo(t[i]) * rstd), bfhi(g[i]) * rbf(bfhi(t[i]) * rstd));
+      xf[s] = __builtin_bit_cast(bf16x8_t, o);
+    }
+  }
+
   for (; tile < n_tiles; tile += gridDim.x, ++it) {
     const int next_tile = tile + gridDim.x;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -94,8 +134,11 @@ template <int KS, int GS, int EPI>
 int launch_ks(const GemmArgs& a, hipStream_t s) {
   const int n_tiles = a.N / 16;
   const int per_cu = (KS <= 24) ? 2 : 1;          // x fragments cost 4·KS VGPRs per lane
-  const int grid = n_tiles < 256 * per_cu ? n_tiles : 256 * per_cu;
-  hipLaunchKernelGGL((gemm_skinny_kernel<KS, GS, EPI>), dim3(grid), dim3(NW * 64), 0, s, a, n_tiles);
+  // balanced tiles per workgroup: e.g. 768 tiles on 512 slots → 384 workgroups × 2 tiles (not 256 × 2 + 256 × 1)
+  const int tpw = (n_tiles + 256 * per_cu - 1) / (256 * per_cu);
+  const int grid = (n_tiles + tpw - 1) / tpw;
+  if (a.norm_w) hipLaunchKernelGGL((gemm_skinny_kernel<KS, GS, EPI, true>), dim3(grid), dim3(NW * 64), 0, s, a, n_tiles);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<KS, GS, EPI, false>), dim3(grid), dim3(NW * 64), 0, s, a, n_tiles);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

@@ -73,6 +73,7 @@ class OpenVLAEngine:
         self.xd, self.hd, self.aod = z(B, D), z(B, D), z(B, D)
         self.qkvd, self.actd = z(B, 3 * D), z(B, I)
         self.cos, self.sin = rope_tables(d.head_dim, d.max_pos, d.rope_theta, dev)
+        self.ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)   # split-K scratch shared by all GEMMs (one stream)
         self.key_mask = torch.ones(B, S, dtype=torch.uint8, device=dev) if use_mask else None
         self.logits_all = z(B * S, d.vocab, dtype=torch.float32) if all_rows else None
 
@@ -81,6 +82,9 @@ class OpenVLAEngine:
         self.prefill_ops = self._plan_prefill()
         self.decode_ops = [self._plan_decode(t) for t in range(1, n_new)]
         self._graph: Optional[torch.cuda.CUDAGraph] = None
+
+    def _g(self, *args, **kw):
+        return ops.gemm(*args, workspace=self.ws, **kw)
 
     # ---- plans ----------------------------------------------------------------------------------------------------
     def _plan_tower(self, tw: TowerW, feat_col: int) -> List[Op]:
@@ -97,32 +101,32 @@ class OpenVLAEngine:
         if tw.prefix is not None:
             plan.append(ops.write_prefix_tokens(tw.prefix, x, B, T, run=False))
         # patch-embed GEMM + bias + pos-embed, rows written behind the prefix tokens
-        plan.append(ops.gemm(self.v_col, tw.patch_w, x, EPI_BIAS_RES, bias=tw.patch_b, res=tw.pos, res_row_mod=256,
+        plan.append(self._g(self.v_col, tw.patch_w, x, EPI_BIAS_RES, bias=tw.patch_b, res=tw.pos, res_row_mod=256,
                              out_map=(256, T, t.n_prefix), algo_nk=(Dm, self.dims.patch_k), run=False))
         st = (T * 3 * Dm, hd, 3 * Dm)
         for i, b in enumerate(tw.blocks):
             plan.append(ops.layernorm(x, b.norm1_w, b.norm1_b, h, self.dims.ln_eps, run=False))
-            plan.append(ops.gemm(h, b.qkv_w, qkv, EPI_BIAS, bias=b.qkv_b, run=False))
+            plan.append(self._g(h, b.qkv_w, qkv, EPI_BIAS, bias=b.qkv_b, run=False))
             plan.append(ops.attention(qkv, qkv[:, Dm:], qkv[:, 2 * Dm:], ao, B=B, H=t.heads, Sq=T, Skv=T, head_dim=hd,
                                       q_strides=st, k_strides=st, v_strides=st, o_strides=(T * Dm, hd, Dm),
                                       causal=False, run=False))
-            plan.append(ops.gemm(ao, b.proj_w, x, EPI_BIAS_RES, bias=b.proj_b, scale=b.ls1, res=x, run=False))
+            plan.append(self._g(ao, b.proj_w, x, EPI_BIAS_RES, bias=b.proj_b, scale=b.ls1, res=x, run=False))
             plan.append(ops.layernorm(x, b.norm2_w, b.norm2_b, h, self.dims.ln_eps, run=False))
-            plan.append(ops.gemm(h, b.fc1_w, mlp, EPI_BIAS_GELU, bias=b.fc1_b, algo_nk=(t.mlp, Dm), run=False))
+            plan.append(self._g(h, b.fc1_w, mlp, EPI_BIAS_GELU, bias=b.fc1_b, algo_nk=(t.mlp, Dm), run=False))
             if i + 1 < len(tw.blocks):
-                plan.append(ops.gemm(mlp, b.fc2_w, x, EPI_BIAS_RES, bias=b.fc2_b, scale=b.ls2, res=x, algo_nk=(Dm, t.mlp),
+                plan.append(self._g(mlp, b.fc2_w, x, EPI_BIAS_RES, bias=b.fc2_b, scale=b.ls2, res=x, algo_nk=(Dm, t.mlp),
                                      run=False))
             else:   # tap: drop the prefix tokens and write this tower's channels of the fused feature map
-                plan.append(ops.gemm(mlp, b.fc2_w, self.feats[:, feat_col:feat_col + Dm], EPI_BIAS_RES, bias=b.fc2_b,
+                plan.append(self._g(mlp, b.fc2_w, self.feats[:, feat_col:feat_col + Dm], EPI_BIAS_RES, bias=b.fc2_b,
                                      scale=b.ls2, res=x, out_map=(T, 256, -t.n_prefix), algo_nk=(Dm, t.mlp), run=False))
         return plan
 
     def _plan_projector(self) -> List[Op]:
         """PrismaticProjector (modeling_prismatic.py:151-156); fc3 writes straight into LLM embedding rows 1..256."""
         w, B, S, D = self.w, self.B, self.S, self.dims.llm_dim
-        return [ops.gemm(self.feats, w.fc1_w, self.p1, EPI_BIAS_GELU, bias=w.fc1_b, run=False),
-                ops.gemm(self.p1, w.fc2_w, self.p2, EPI_BIAS_GELU, bias=w.fc2_b, run=False),
-                ops.gemm(self.p2, w.fc3_w, self.x.view(B * S, D), EPI_BIAS, bias=w.fc3_b, out_map=(256, S, 1), run=False)]
+        return [self._g(self.feats, w.fc1_w, self.p1, EPI_BIAS_GELU, bias=w.fc1_b, run=False),
+                self._g(self.p1, w.fc2_w, self.p2, EPI_BIAS_GELU, bias=w.fc2_b, run=False),
+                self._g(self.p2, w.fc3_w, self.x.view(B * S, D), EPI_BIAS, bias=w.fc3_b, out_map=(256, S, 1), run=False)]
 
     def _plan_prefill(self) -> List[Op]:
         d, w, B, S = self.dims, self.w, self.B, self.S
@@ -132,49 +136,67 @@ class OpenVLAEngine:
         cs = (H * self.cache_len * hd, self.cache_len * hd, hd)
         for l, lw in enumerate(w.layers):
             plan.append(ops.rmsnorm(x, lw.ln1, self.h, d.rms_eps, run=False))
-            plan.append(ops.gemm(self.h, lw.qkv_w, self.qkv, EPI_NONE, run=False))
+            plan.append(self._g(self.h, lw.qkv_w, self.qkv, EPI_NONE, run=False))
             plan.append(ops.rope_kvcache(self.qkv, self.cos, self.sin, self.k_cache[l], self.v_cache[l], B=B, S=S, H=H,
                                          head_dim=hd, pos0=0, run=False))
             plan.append(ops.attention(self.qkv, self.k_cache[l], self.v_cache[l], self.ao, B=B, H=H, Sq=S, Skv=S,
                                       head_dim=hd, q_strides=(S * 3 * D, hd, 3 * D), k_strides=cs, v_strides=cs,
                                       o_strides=(S * D, hd, D), causal=True, key_mask=self.key_mask, run=False))
-            plan.append(ops.gemm(self.ao, lw.o_w, x, EPI_RES, res=x, run=False))
+            plan.append(self._g(self.ao, lw.o_w, x, EPI_RES, res=x, run=False))
             plan.append(ops.rmsnorm(x, lw.ln2, self.h, d.rms_eps, run=False))
-            plan.append(ops.gemm(self.h, lw.gu_w, self.act, EPI_SWIGLU, run=False))
-            plan.append(ops.gemm(self.act, lw.down_w, x, EPI_RES, res=x, run=False))
+            plan.append(self._g(self.h, lw.gu_w, self.act, EPI_SWIGLU, run=False))
+            plan.append(self._g(self.act, lw.down_w, x, EPI_RES, res=x, run=False))
         if self.all_rows:   # HF semantics: logits for every position (what forward()/training consume)
             plan.append(ops.rmsnorm(x, w.norm, self.h, d.rms_eps, run=False))
-            plan.append(ops.gemm(self.h, w.lm_head, self.logits_all, EPI_F32_BF16R, run=False))
+            plan.append(self._g(self.h, w.lm_head, self.logits_all, EPI_F32_BF16R, run=False))
             return plan
         # final norm + lm_head on the last position only (the reference materialises all S rows)
         last = self.x[:, S - 1, :]
-        plan.append(ops.rmsnorm(last, w.norm, self.hd, d.rms_eps, run=False))
-        plan.append(ops.gemm(self.hd, w.lm_head, self.logits[0], EPI_F32_BF16R, run=False))
-        plan.append(ops.argmax(self.logits[0], self.gen_ids[0], run=False))
+        plan += self._head(last, 0)
+        return plan
+
+    def _head(self, x_rows: torch.Tensor, t: int) -> List[Op]:
+        """final RMSNorm → lm_head (bf16-rounded fp32 logits) → greedy argmax, for generation step t."""
+        d, w = self.dims, self.w
+        if ops.skinny_supported(self.B, d.llm_dim, EPI_F32_BF16R):   # RMSNorm fused into the weight-streaming GEMM
+            plan = [self._g(x_rows, w.lm_head, self.logits[t], EPI_F32_BF16R, a_norm=(w.norm, d.rms_eps), run=False)]
+        else:
+            plan = [ops.rmsnorm(x_rows, w.norm, self.hd, d.rms_eps, run=False),
+                    self._g(self.hd, w.lm_head, self.logits[t], EPI_F32_BF16R, run=False)]
+        plan.append(ops.argmax(self.logits[t], self.gen_ids[t], run=False))
         return plan
 
     def _plan_decode(self, t: int) -> List[Op]:
-        """Cached-generation step t (modeling_prismatic.py:325-341): token gen_ids[t-1] at position S+t-1."""
+        """Cached-generation step t (modeling_prismatic.py:325-341): token gen_ids[t-1] at position S+t-1. Five
+        launches per layer: qkv (RMSNorm fused) → attention (RoPE + KV append fused) → o_proj+residual → gate/up
+        (RMSNorm + SwiGLU fused) → down+residual."""
         d, w, B = self.dims, self.w, self.B
         D, H, hd = d.llm_dim, d.llm_heads, d.head_dim
         pos = self.S + t - 1
+        fused = ops.skinny_supported(B, D, EPI_NONE) and hd == 128
         cs = (H * self.cache_len * hd, self.cache_len * hd, hd)
         plan = [ops.embed_splice(self.gen_ids[t - 1].view(B, 1), w.embed, self.xd.view(B, 1, D), 0, run=False)]
         for l, lw in enumerate(w.layers):
-            plan.append(ops.rmsnorm(self.xd, lw.ln1, self.hd, d.rms_eps, run=False))
-            plan.append(ops.gemm(self.hd, lw.qkv_w, self.qkvd, EPI_NONE, run=False))
-            plan.append(ops.rope_kvcache(self.qkvd, self.cos, self.sin, self.k_cache[l], self.v_cache[l], B=B, S=1, H=H,
-                                         head_dim=hd, pos0=pos, run=False))
-            plan.append(ops.attention_decode(self.qkvd, self.k_cache[l], self.v_cache[l], self.aod, B=B, H=H,
-                                             Skv=pos + 1, head_dim=hd, q_strides=(3 * D, hd, 3 * D), k_strides=cs,
-                                             v_strides=cs, o_strides=(D, hd, D), run=False))
-            plan.append(ops.gemm(self.aod, lw.o_w, self.xd, EPI_RES, res=self.xd, run=False))
-            plan.append(ops.rmsnorm(self.xd, lw.ln2, self.hd, d.rms_eps, run=False))
-            plan.append(ops.gemm(self.hd, lw.gu_w, self.actd, EPI_SWIGLU, run=False))
-            plan.append(ops.gemm(self.actd, lw.down_w, self.xd, EPI_RES, res=self.xd, run=False))
-        plan.append(ops.rmsnorm(self.xd, w.norm, self.hd, d.rms_eps, run=False))
-        plan.append(ops.gemm(self.hd, w.lm_head, self.logits[t], EPI_F32_BF16R, run=False))
-        plan.append(ops.argmax(self.logits[t], self.gen_ids[t], run=False))
+            if fused:
+                plan.append(self._g(self.xd, lw.qkv_w, self.qkvd, EPI_NONE, a_norm=(lw.ln1, d.rms_eps), run=False))
+                plan.append(ops.attention_decode_rope(self.qkvd, self.k_cache[l], self.v_cache[l], self.aod, self.cos,
+                                                      self.sin, B=B, H=H, head_dim=hd, pos=pos, run=False))
+            else:
+                plan.append(ops.rmsnorm(self.xd, lw.ln1, self.hd, d.rms_eps, run=False))
+                plan.append(self._g(self.hd, lw.qkv_w, self.qkvd, EPI_NONE, run=False))
+                plan.append(ops.rope_kvcache(self.qkvd, self.cos, self.sin, self.k_cache[l], self.v_cache[l], B=B, S=1,
+                                             H=H, head_dim=hd, pos0=pos, run=False))
+                plan.append(ops.attention_decode(self.qkvd, self.k_cache[l], self.v_cache[l], self.aod, B=B, H=H,
+                                                 Skv=pos + 1, head_dim=hd, q_strides=(3 * D, hd, 3 * D), k_strides=cs,
+                                                 v_strides=cs, o_strides=(D, hd, D), run=False))
+            plan.append(self._g(self.aod, lw.o_w, self.xd, EPI_RES, res=self.xd, run=False))
+            if fused:
+                plan.append(self._g(self.xd, lw.gu_w, self.actd, EPI_SWIGLU, a_norm=(lw.ln2, d.rms_eps), run=False))
+            else:
+                plan.append(ops.rmsnorm(self.xd, lw.ln2, self.hd, d.rms_eps, run=False))
+                plan.append(self._g(self.hd, lw.gu_w, self.actd, EPI_SWIGLU, run=False))
+            plan.append(self._g(self.actd, lw.down_w, self.xd, EPI_RES, res=self.xd, run=False))
+        plan += self._head(self.xd, t)
         return plan
 
     # ---- execution ------------------------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import (AttnDesc, GemmDesc, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_F32, EPI_F32_BF16R, EPI_NONE,
                    EPI_RES, EPI_SWIGLU)
 
-__all__ = ["Op", "gemm", "pack_weight", "unpack_weight", "cross_entropy", "layernorm", "rmsnorm", "attention", "attention_decode", "rope_kvcache", "embed_splice",
+__all__ = ["Op", "gemm", "pack_weight", "unpack_weight", "cross_entropy", "layernorm", "rmsnorm", "attention", "attention_decode", "attention_decode_rope", "skinny_supported", "rope_kvcache", "embed_splice",
            "argmax", "im2col_patch14", "write_prefix_tokens", "fill_synth", "run_all",
            "EPI_NONE", "EPI_BIAS", "EPI_BIAS_GELU", "EPI_BIAS_RES", "EPI_RES", "EPI_SWIGLU", "EPI_F32", "EPI_F32_BF16R"]
 
@@ -81,17 +81,27 @@ def unpack_weight(wp: torch.Tensor) -> torch.Tensor:
     return wp.view(nt, ks, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(nt * 16, ks * 32)
 
 
+def skinny_supported(M: int, K: int, epilogue: int) -> bool:
+    """Shapes the weight-streaming kernel is instantiated for (gemm_skinny.hip::launch_skinny)."""
+    return (M <= 16 and K in (512, 1024, 1536, 4096, 5120, 11008, 13824)
+            and epilogue in (EPI_NONE, EPI_RES, EPI_SWIGLU, EPI_F32, EPI_F32_BF16R))
+
+
 def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, *,
          bias: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
          res: Optional[torch.Tensor] = None, res_row_mod: int = 0,
          out_map: Optional[Tuple[int, int, int]] = None,
-         skinny: Optional[bool] = None, algo_nk: Optional[Tuple[int, int]] = None, run: bool = True) -> Op:
+         skinny: Optional[bool] = None, algo_nk: Optional[Tuple[int, int]] = None,
+         a_norm: Optional[Tuple[torch.Tensor, float]] = None, workspace: Optional[torch.Tensor] = None,
+         run: bool = True) -> Op:
     """out = epilogue(A @ W.T).  A [M,K] row-major activations; W = PACKED weight [N/16, K/32, 64, 8] (pack_weight);
     out [rows, N] (N/2 for SWIGLU; fp32 for F32*).
 
     `out_map=(group, stride, offset)` remaps output rows (see bl_gemm_desc).
     `skinny=None` picks the weight-streaming kernel automatically for M <= 16 when it supports K.
     `algo_nk=(N, K)` gives the un-padded logical sizes for FLOP accounting when N or K carry zero padding.
+    `a_norm=(weight, eps)` fuses HF LlamaRMSNorm on the rows of A (skinny kernel only: M <= 16).
+    `workspace`: optional scratch tensor (>= 64 MiB) enabling the split-K tail of the 256x256 kernel.
     """
     lib = _lib.load()
     _bf16(A, "A"); _bf16(W, "W")
@@ -119,6 +129,9 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, epilogue: int = EP
     d.res_row_mod = res_row_mod
     if out_map is not None:
         d.out_group, d.out_stride, d.out_offset = out_map
+    if workspace is not None:
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+        keep.append(workspace)
     n_out = N // 2 if epilogue == EPI_SWIGLU else N
     if out.shape[1] < n_out:
         raise ValueError(f"gemm: out has {out.shape[1]} columns, needs {n_out}")
@@ -126,8 +139,12 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, epilogue: int = EP
         raise ValueError(f"gemm: out has {out.shape[0]} rows, needs {M}")
     use_skinny = skinny
     if use_skinny is None:
-        use_skinny = (M <= 16 and K in (512, 1024, 1536, 4096, 5120, 11008, 13824)
-                      and epilogue in (EPI_NONE, EPI_RES, EPI_SWIGLU, EPI_F32, EPI_F32_BF16R))
+        use_skinny = skinny_supported(M, K, epilogue)
+    if a_norm is not None:
+        if not use_skinny:
+            raise ValueError("gemm: a_norm (fused RMSNorm) needs the skinny kernel (M <= 16 and a supported K)")
+        d.a_norm_weight, d.a_norm_eps = _bf16(a_norm[0], "a_norm weight").data_ptr(), float(a_norm[1])
+        keep.append(a_norm[0])
     fn = lib.bl_gemm_skinny_bf16 if use_skinny else lib.bl_gemm_bf16
     # algorithmic work: logical FLOPs; bytes = each operand once + the output once
     esz = 4 if epilogue in (EPI_F32, EPI_F32_BF16R) else 2
@@ -200,6 +217,32 @@ def attention_decode(q, k, v, o, *, B: int, H: int, Skv: int, head_dim: int, q_s
     d = _attn_desc(q, k, v, o, B, H, 1, Skv, head_dim, q_strides, k_strides, v_strides, o_strides, False, scale,
                    key_mask)
     op = Op("bl_attention_decode_bf16", lib.bl_attention_decode_bf16, (C.byref(d),), (d, q, k, v, o, key_mask))
+    if run:
+        op.run()
+    return op
+
+
+def attention_decode_rope(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, o: torch.Tensor,
+                          cos: torch.Tensor, sin: torch.Tensor, *, B: int, H: int, head_dim: int, pos: int,
+                          scale: Optional[float] = None, key_mask: Optional[torch.Tensor] = None, run: bool = True) -> Op:
+    """One decode step's attention with RoPE and the KV-cache append fused: qkv [B, 3*H*hd] is the step's fused
+    projection (q | k | v), caches [B, H, cache_len, hd]; rotates q and k at `pos`, writes k', v to cache row `pos`,
+    attends over keys 0..pos, writes o [B, H*hd]."""
+    lib = _lib.load()
+    D = H * head_dim
+    for t, n in ((qkv, "qkv"), (k_cache, "k_cache"), (v_cache, "v_cache"), (cos, "cos"), (sin, "sin")):
+        _bf16(t, n)
+        if not t.is_contiguous():
+            raise ValueError(f"attention_decode_rope: {n} must be contiguous")
+    cache_len = k_cache.shape[2]
+    if pos >= cache_len or pos >= cos.shape[0]:
+        raise ValueError("attention_decode_rope: position outside the cache / rope table")
+    scale = head_dim ** -0.5 if scale is None else scale
+    cs = (H * cache_len * head_dim, cache_len * head_dim, head_dim)
+    d = _attn_desc(qkv, k_cache, v_cache, o, B, H, 1, pos + 1, head_dim, (3 * D, head_dim, 3 * D), cs, cs,
+                   (D, head_dim, D), False, scale, key_mask)
+    op = Op("bl_attention_decode_rope_bf16", lib.bl_attention_decode_rope_bf16,
+            (C.byref(d), cos.data_ptr(), sin.data_ptr(), pos), (d, qkv, k_cache, v_cache, o, cos, sin, key_mask))
     if run:
         op.run()
     return op

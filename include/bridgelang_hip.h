@@ -84,6 +84,15 @@ typedef struct bl_gemm_desc {
    * (modeling_prismatic.py:85-87,121-123) and to write projector output straight into LLM embedding rows 1..256
    * (modeling_prismatic.py:383-385). */
   int32_t out_group, out_stride, out_offset;
+  /* Optional fused HF LlamaRMSNorm on the A operand (bl_gemm_skinny_bf16 only): A rows are normalised in registers as
+   * t = bf16(a * rsqrt(mean(a^2) + eps)), a' = bf16(a_norm_weight[k] * t) before the product. NULL = off. */
+  const bl_bf16* a_norm_weight;
+  float a_norm_eps;
+  /* Optional scratch for bl_gemm_bf16's split-K tail (fp32 partial tiles of the last, partially filled round of
+   * 256x256 tiles); 64 MiB always suffices. NULL / too small → the tail runs as 128x128 tiles instead. Contents are
+   * undefined after the call; calls that share a workspace must be ordered on one stream. */
+  void* workspace;
+  int64_t workspace_bytes;
 } bl_gemm_desc;
 
 int bl_gemm_bf16(const bl_gemm_desc* d, void* stream);
@@ -119,6 +128,13 @@ typedef struct bl_attn_desc {
 int bl_attention_bf16(const bl_attn_desc* d, void* stream);
 /* Single-query decode attention over a KV cache; kv_len = number of valid keys (same for the whole batch). */
 int bl_attention_decode_bf16(const bl_attn_desc* d, void* stream);
+
+/* Decode attention with the rotary embedding and the KV-cache append of the NEW token fused in: q / k_new / v_new are
+ * the three thirds of the step's fused qkv row (strides d->q_*; k_new = q + H*hd, v_new = q + 2*H*hd elements). q and
+ * k_new are rotated at position `pos` (HF apply_rotary_pos_emb, bf16 roundings as bl_rope_kvcache_bf16), k_new', v_new
+ * are written to cache row `pos` of d->k / d->v, and attention runs over keys 0..pos (d->Skv must equal pos + 1). */
+int bl_attention_decode_rope_bf16(const bl_attn_desc* d, const bl_bf16* cos_tab, const bl_bf16* sin_tab, int32_t pos,
+                                  void* stream);
 
 /* ---- Llama glue -------------------------------------------------------------------------------------------- */
 /* Half-split RoPE (HF apply_rotary_pos_emb) on the q and k thirds of a fused qkv buffer [B*S, 3*H*hd], bf16 cos/sin

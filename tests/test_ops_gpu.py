@@ -108,6 +108,36 @@ def test_gemm_none_bias_gelu(dev, M, N, K):
     close_bf16(outf, R.linear(P, a, w), "EPI_F32_BF16R")
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(4608, 4096, 512, "res"), (4608, 1024, 1024, "gelu"), (4400, 3584, 768, "swiglu"),
+                                       (4608, 12288, 256, "none")])
+def test_gemm_splitk_tail(dev, M, N, K, epi):
+    """Shapes whose 256x256 tile count is not a multiple of 256: whole rounds + split-K tail (with a workspace) must
+    equal the oracle, and equal the no-workspace dispatch bit for bit except for fp32 summation order."""
+    from bridgelang_amd import ops
+    a, w, b, r = rand_bf16((M, K), 1), rand_bf16((N, K), 2, 0.05), rand_bf16((N,), 3, 0.1), rand_bf16((M, N), 4)
+    A, Bv, Rr = dv(a, dev), dv(b, dev), dv(r, dev)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    if epi == "swiglu":
+        I = N // 2
+        W = pk(torch.stack([w[:I], w[I:]], 1).reshape(N, K), dev)
+        out, out2 = (torch.zeros(M, I, dtype=torch.bfloat16, device=dev) for _ in range(2))
+        ops.gemm(A, W, out, ops.EPI_SWIGLU, workspace=ws)
+        ops.gemm(A, W, out2, ops.EPI_SWIGLU)
+        g, u = R.linear(P, a, w[:I]), R.linear(P, a, w[I:])
+        ref = P.rb(P.rb(torch.nn.functional.silu(g)) * u)
+    else:
+        W = pk(w, dev)
+        out, out2 = (torch.zeros(M, N, dtype=torch.bfloat16, device=dev) for _ in range(2))
+        code = {"res": ops.EPI_RES, "gelu": ops.EPI_BIAS_GELU, "none": ops.EPI_NONE}[epi]
+        kw = {"res": dict(res=Rr), "gelu": dict(bias=Bv), "none": {}}[epi]
+        ops.gemm(A, W, out, code, workspace=ws, **kw)
+        ops.gemm(A, W, out2, code, **kw)
+        lin = R.linear(P, a, w, b if epi == "gelu" else None)
+        ref = {"res": lambda: P.rb(r + lin), "gelu": lambda: R.gelu(P, lin), "none": lambda: lin}[epi]()
+    close_bf16(out, ref, f"split-K tail {epi}")
+    close_bf16(out, out2.cpu().float(), "split-K vs 128-tail dispatch", min_exact=0.97)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 192, 128), (522, 256, 1088), (1305, 768, 448)])
 def test_gemm_residual_layerscale_swiglu(dev, M, N, K):
     from bridgelang_amd import ops

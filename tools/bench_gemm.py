@@ -16,6 +16,7 @@ shapes = [("llama qkv", M_LLM, 12288, 4096, ops.EPI_NONE), ("llama o", M_LLM, 40
           ("square 8k", 8192, 8192, 8192, ops.EPI_NONE), ("square 4k", 4096, 4096, 4096, ops.EPI_NONE)]
 print("tile =", os.environ.get("BL_GEMM_TILE", "auto"))
 tot = 0.0
+ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
 for name, M, N, K, epi in shapes:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = ops.pack_weight((torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16))
@@ -26,7 +27,7 @@ for name, M, N, K, epi in shapes:
     kw = {}
     if epi in (ops.EPI_BIAS, ops.EPI_BIAS_GELU, ops.EPI_BIAS_RES): kw["bias"] = bias
     if epi in (ops.EPI_RES, ops.EPI_BIAS_RES): kw["res"] = res
-    op = ops.gemm(a, w, out, epi, run=False, **kw)
+    op = ops.gemm(a, w, out, epi, run=False, workspace=ws, **kw)
     for _ in range(3): op.run()
     torch.cuda.synchronize()
     reps = 20
