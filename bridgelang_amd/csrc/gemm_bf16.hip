@@ -309,6 +309,208 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #endif
 }
 
+// ======================================================================================================================
+// 256 × 256 tile, STAGGERED wave groups: waves 0-3 (group A, wm = 0) and waves 4-7 (group B, wm = 1) share each SIMD
+// pairwise; running them half a phase apart lets one group's 16 MFMAs cover the other group's LDS-DMA issue and
+// fragment reads, so the matrix pipe no longer idles while both waves of a SIMD load in lockstep
+// (square 8k: 1328 → 1430 TFLOP/s; Llama layer GEMMs 1719 → 1594 µs).
+//
+//   segment 2p   : A: MMA(p)                      B: ISSUE H(p+6), READ(p)
+//   segment 2p+1 : A: ISSUE H(p+6), READ(p+1)     B: MMA(p)                       (one raw s_barrier after every segment)
+//
+// p = global phase (4 per K-tile, quadrants (0,0)(0,1)(1,1)(1,0)); H(p) = the half-tile first read for phase p:
+// X0(t), Y1(t), X1(t), Y0(t+1). Half-tiles are issued 6 phases ahead in need order; H(p+1) must be complete before
+// segment 2p+1, so at the end of segment 2p group A (issued up to H(p+5)) waits vmcnt(8) and group B (up to H(p+6))
+// vmcnt(10). A buffer is re-issued ≥ 2 barriers after its last read. Fragments: one activation set (X), two weight sets.
+// (Tried and rejected: prefetching the next phase's fragments inside the group's own MMA segment — hipcc serialises the
+// reads ahead of the MFMAs, the MMA segment grows, 1430 → 1286 TFLOP/s.)
+// ======================================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 256, BN = 256;
+  constexpr int STAGE = 65536, W_OFF = 32768;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  int tm, tn;
+  const int nk_all = p.K / BK;
+  int kt_begin = 0, nk = nk_all;
+  if (p.splitk > 1) {
+    lin_to_tile(p, p.tail_base + blockIdx.x / p.splitk, tm, tn);
+    const int slice = blockIdx.x % p.splitk;
+    kt_begin = (int)(((long)slice * nk_all) / p.splitk) & ~1;
+    nk = slice + 1 == p.splitk ? nk_all : ((int)(((long)(slice + 1) * nk_all) / p.splitk) & ~1);
+  } else {
+    tile_coords(p, tm, tn);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int kt32 = p.K >> 5;
+
+  const unsigned a_bytes = (unsigned)min((long)p.M * p.lda * 2, 0xffffffffL);
+  const unsigned w_bytes = (unsigned)min((long)p.N * p.K * 2, 0xffffffffL);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0, 0x00020000);
+
+  const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
+  unsigned voffX[2][2], voffY[2][2];
+  int ldsX[2][2], ldsY[2];
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pi = 2 * wave + j, row0 = (pi >> 3) * 128 + mh * 64 + (pi & 7) * 8;
+      voffX[mh][j] = (unsigned)(((long)(m0 + row0 + prow) * p.lda) * 2 + pchunk * 16);
+      ldsX[mh][j] = row0 * ROW_BYTES;
+    }
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    const int nt = (wave >> 1) * 4 + 2 * nh + (wave & 1);
+    voffY[nh][0] = (unsigned)((long)(n0 / 16 + nt) * kt32 * 1024 + lane * 16);
+    voffY[nh][1] = voffY[nh][0] + 1024;
+    ldsY[nh] = W_OFF + nt * 2048;
+  }
+#define ISSUE_X(MH, TILE)                                                                   \
+  do {                                                                                      \
+    const int t__ = (TILE);                                                                 \
+    const __amdgpu_buffer_rsrc_t rs__ = t__ < nk ? rsA : rsA0;                              \
+    char* b__ = smem + (t__ & 1) * STAGE;                                                   \
+    BL_GLDS(rs__, b__ + ldsX[MH][0], voffX[MH][0], t__ * 128);                              \
+    BL_GLDS(rs__, b__ + ldsX[MH][1], voffX[MH][1], t__ * 128);                              \
+  } while (0)
+#define ISSUE_Y(NH, TILE)                                                                   \
+  do {                                                                                      \
+    const int t__ = (TILE);                                                                 \
+    const __amdgpu_buffer_rsrc_t rs__ = t__ < nk ? rsW : rsW0;                              \
+    char* b__ = smem + (t__ & 1) * STAGE;                                                   \
+    BL_GLDS(rs__, b__ + ldsY[NH], voffY[NH][0], t__ * 2048);                                \
+    BL_GLDS(rs__, b__ + ldsY[NH] + 1024, voffY[NH][1], t__ * 2048);                         \
+  } while (0)
+  const int cb0 = (lg ^ (lane & 7)) << 4;
+  const int offX = (wm * 128 + l15) * ROW_BYTES;
+  const int offY = W_OFF + wn * 8192 + lane * 16;
+#define READ_X(DST, MH, SB)                                                                             \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+    DST[i * 2] = *(const bf16x8_t*)((SB) + offX + (MH) * 8192 + i * 2048 + cb0);                        \
+    DST[i * 2 + 1] = *(const bf16x8_t*)((SB) + offX + (MH) * 8192 + i * 2048 + (cb0 ^ 64));            \
+  }
+#define READ_Y(DST, NH, SB)                                                                             \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
+    DST[j * 2] = *(const bf16x8_t*)((SB) + offY + (2 * (NH) + j) * 2048);                               \
+    DST[j * 2 + 1] = *(const bf16x8_t*)((SB) + offY + (2 * (NH) + j) * 2048 + 1024);                    \
+  }
+#define MMA(XR, YR, MH, NH)                                                                             \
+  do {                                                                                                  \
+    __builtin_amdgcn_s_setprio(1);                                                                      \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
+          acc[2 * (NH) + j][4 * (MH) + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                    \
+              YR[j * 2 + ks], XR[i * 2 + ks], acc[2 * (NH) + j][4 * (MH) + i], 0, 0, 0);                \
+    __builtin_amdgcn_s_setprio(0);                                                                      \
+  } while (0)
+#define BAR()                                   \
+  do {                                          \
+    __builtin_amdgcn_s_barrier();               \
+    __builtin_amdgcn_sched_barrier(0);          \
+  } while (0)
+#define WAIT_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define WAIT_VM10_LGKM() asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory")
+#define WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+  // H(p+6) for phase q of K-tile T:  q=0 → X1(T+1)   q=1 → Y0(T+2)   q=2 → X0(T+2)   q=3 → Y1(T+2)
+#define ISSUE_Q0(T) ISSUE_X(1, (T) + 1)
+#define ISSUE_Q1(T) ISSUE_Y(0, (T) + 2)
+#define ISSUE_Q2(T) ISSUE_X(0, (T) + 2)
+#define ISSUE_Q3(T) ISSUE_Y(1, (T) + 2)
+  // each group runs its own loop AND its own copy of the epilogue (a common epilogue after an if/else would force the
+  // 128 accumulator registers of both loops into one assignment)
+#define BL_EPILOGUE()                                                                                     \
+  do {                                                                                                    \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+    if (p.splitk > 1) {                                                                                   \
+      float* dst = p.slab + ((long)blockIdx.x * 32 * 512 + tid) * 4;                                      \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) *(f32x4_t*)(dst + (long)(i * 8 + j) * 512 * 4) = acc[i][j]; \
+    } else {                                                                                              \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                     \
+          epilogue_store4<EPI>(p, m0 + wm * 128 + j * 16 + l15, n0 + wn * 64 + i * 16 + lg * 4, acc[i][j]); \
+    }                                                                                                     \
+  } while (0)
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  bf16x8_t X[8], Ya[4], Yb[4];
+  char* const S0 = smem;
+  char* const S1 = smem + STAGE;
+  const int t0 = kt_begin;
+
+  // ---- prologue: H(-1) = Y0(t0), H(0) = X0(t0), H(1) = Y1(t0), H(2) = X1(t0), H(3) = Y0(t0+1), H(4) = X0(t0+1),
+  //      H(5) = Y1(t0+1); the first two must have landed before the first reads ----
+  ISSUE_Y(0, t0); ISSUE_X(0, t0); ISSUE_Y(1, t0); ISSUE_X(1, t0); ISSUE_Y(0, t0 + 1); ISSUE_X(0, t0 + 1); ISSUE_Y(1, t0 + 1);
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  BAR();
+  READ_Y(Ya, 0, S0);
+
+  if (wm == 0) {
+    // ============================== group A: MMA first, then issue + read the NEXT phase ==============================
+    READ_X(X, 0, S0);
+    WAIT_LGKM();
+    BAR();
+    for (int t = t0; t < nk; t += 2) {
+      // K-tile t (stage 0): Y0 in Ya, Y1 → Yb
+      MMA(X, Ya, 0, 0); WAIT_VM8(); BAR();   ISSUE_Q0(t);     READ_Y(Yb, 1, S0); WAIT_LGKM(); BAR();
+      MMA(X, Yb, 0, 1); WAIT_VM8(); BAR();   ISSUE_Q1(t);     READ_X(X, 1, S0);  WAIT_LGKM(); BAR();
+      MMA(X, Yb, 1, 1); WAIT_VM8(); BAR();   ISSUE_Q2(t);     READ_Y(Yb, 0, S1); WAIT_LGKM(); BAR();
+      MMA(X, Ya, 1, 0); WAIT_VM8(); BAR();   ISSUE_Q3(t);     READ_X(X, 0, S1);  WAIT_LGKM(); BAR();
+      // K-tile t+1 (stage 1): Y0 in Yb, Y1 → Ya
+      MMA(X, Yb, 0, 0); WAIT_VM8(); BAR();   ISSUE_Q0(t + 1); READ_Y(Ya, 1, S1); WAIT_LGKM(); BAR();
+      MMA(X, Ya, 0, 1); WAIT_VM8(); BAR();   ISSUE_Q1(t + 1); READ_X(X, 1, S1);  WAIT_LGKM(); BAR();
+      MMA(X, Ya, 1, 1); WAIT_VM8(); BAR();   ISSUE_Q2(t + 1); READ_Y(Ya, 0, S0); WAIT_LGKM(); BAR();
+      MMA(X, Yb, 1, 0); WAIT_VM8(); BAR();   ISSUE_Q3(t + 1); READ_X(X, 0, S0);  WAIT_LGKM(); BAR();
+    }
+    BL_EPILOGUE();
+    return;
+  }
+  // ============================== group B: issue + read THIS phase, then MMA ==============================
+  WAIT_LGKM();
+  BAR();
+  for (int t = t0; t < nk; t += 2) {
+    ISSUE_Q0(t);     READ_X(X, 0, S0);  WAIT_VM10_LGKM(); BAR();   MMA(X, Ya, 0, 0); BAR();
+    ISSUE_Q1(t);     READ_Y(Yb, 1, S0); WAIT_VM10_LGKM(); BAR();   MMA(X, Yb, 0, 1); BAR();
+    ISSUE_Q2(t);     READ_X(X, 1, S0);  WAIT_VM10_LGKM(); BAR();   MMA(X, Yb, 1, 1); BAR();
+    ISSUE_Q3(t);     READ_Y(Yb, 0, S1); WAIT_VM10_LGKM(); BAR();   MMA(X, Ya, 1, 0); BAR();
+    ISSUE_Q0(t + 1); READ_X(X, 0, S1);  WAIT_VM10_LGKM(); BAR();   MMA(X, Yb, 0, 0); BAR();
+    ISSUE_Q1(t + 1); READ_Y(Ya, 1, S1); WAIT_VM10_LGKM(); BAR();   MMA(X, Ya, 0, 1); BAR();
+    ISSUE_Q2(t + 1); READ_X(X, 1, S1);  WAIT_VM10_LGKM(); BAR();   MMA(X, Ya, 1, 1); BAR();
+    ISSUE_Q3(t + 1); READ_Y(Ya, 0, S0); WAIT_VM10_LGKM(); BAR();   MMA(X, Yb, 1, 0); BAR();
+  }
+  BL_EPILOGUE();
+#undef BL_EPILOGUE
+#undef ISSUE_X
+#undef ISSUE_Y
+#undef READ_X
+#undef READ_Y
+#undef MMA
+#undef BAR
+#undef WAIT_VM8
+#undef WAIT_VM10_LGKM
+#undef WAIT_LGKM
+#undef ISSUE_Q0
+#undef ISSUE_Q1
+#undef ISSUE_Q2
+#undef ISSUE_Q3
+#endif
+}
+
 // Sum the split-K slabs of the leftover tiles and apply the fused epilogue. Same thread → (m, n) map as gemm256_kernel;
 // grid = leftover tiles × 4, each block handles 8 of the 32 accumulator vectors of a tile.
 template <int EPI>
@@ -335,6 +537,8 @@ int set_lds_attr() {
   static bool done = false;   // idempotent; a benign race only repeats the same calls
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * ROW_BYTES) != hipSuccess)
@@ -375,23 +579,30 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (S > 16) S = 16;
   while (S > 1 && nk / S < 4) --S;
   static const bool no_split = getenv("BL_GEMM_NO_SPLITK") != nullptr;
+  static const bool lockstep = getenv("BL_GEMM_LOCKSTEP") != nullptr;   // A/B aid: the non-staggered 256 kernel
+#define BL_LAUNCH256(GRID)                                                                              \
+  do {                                                                                                  \
+    if (lockstep) hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(GRID), dim3(512), LDS256, s, p);       \
+    else hipLaunchKernelGGL((gemm256s_kernel<EPI>), dim3(GRID), dim3(512), LDS256, s, p);               \
+  } while (0)
   const bool can_split = tail && S >= 2 && p.K >= 8192 && p.slab &&
                          p.slab_bytes >= (long)tail * S * 256 * 256 * 4 && !no_split && !force;
   if (can_split) {
     main_tiles = big_tiles - tail;
-    if (main_tiles) hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(main_tiles), dim3(512), LDS256, s, p);
+    if (main_tiles) BL_LAUNCH256(main_tiles);
     p.tail_base = main_tiles;
     p.splitk = S;
-    hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(tail * S), dim3(512), LDS256, s, p);
+    BL_LAUNCH256(tail * S);
     hipLaunchKernelGGL((gemm_splitk_reduce_kernel<EPI>), dim3(tail * 4), dim3(512), 0, s, p);
   } else {
     if (tail != 0 && tail <= 64 && main_tiles > tail && !force) main_tiles = big_tiles - tail; else tail = 0;
-    hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(main_tiles), dim3(512), LDS256, s, p);
+    BL_LAUNCH256(main_tiles);
     if (tail) {
       p.tail_base = main_tiles;
       hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(tail * 4), dim3(256), LDS128, s, p);
     }
   }
+#undef BL_LAUNCH256
   BL_CHECK_LAUNCH();
   return BL_OK;
 }
