@@ -511,26 +511,21 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
 #endif
 }
 
-// Sum the split-K slabs of the leftover tiles and apply the fused epilogue. Same thread → (m, n) map as gemm256_kernel;
-// grid = leftover tiles × 4, each block handles 8 of the 32 accumulator vectors of a tile.
+// Sum the split-K slabs of the leftover tiles and apply the fused epilogue. Same thread → (m, n) map as the 256x256
+// kernels; grid = leftover tiles × 32: one block per accumulator vector (i, j) of a tile, so the slab reads are spread
+// over ≥ 1024 workgroups instead of 128.
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_splitk_reduce_kernel(GemmArgs p) {
   int tm, tn;
-  const int tile_local = blockIdx.x >> 2, part = blockIdx.x & 3;
+  const int tile_local = blockIdx.x >> 5, idx = blockIdx.x & 31, i = idx >> 3, j = idx & 7;
   lin_to_tile(p, p.tail_base + tile_local, tm, tn);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3, l15 = lane & 15, lg = lane >> 4;
-  const int m0 = tm * 256, n0 = tn * 256;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int idx = part * 8 + q, i = idx >> 3, j = idx & 7;
-    f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < p.splitk; ++s)
-      sum += *(const f32x4_t*)(p.slab + (((long)(tile_local * p.splitk + s) * 32 + idx) * 512 + tid) * 4);
-    epilogue_store4<EPI>(p, m0 + wm * 128 + j * 16 + l15, n0 + wn * 64 + i * 16 + lg * 4, sum);
-  }
+  f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < p.splitk; ++s)
+    sum += *(const f32x4_t*)(p.slab + (((long)(tile_local * p.splitk + s) * 32 + idx) * 512 + tid) * 4);
+  epilogue_store4<EPI>(p, tm * 256 + wm * 128 + j * 16 + l15, tn * 256 + wn * 64 + i * 16 + lg * 4, sum);
 }
-#undef BL_GLDS
 
 template <int EPI>
 int set_lds_attr() {
@@ -593,7 +588,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     p.tail_base = main_tiles;
     p.splitk = S;
     BL_LAUNCH256(tail * S);
-    hipLaunchKernelGGL((gemm_splitk_reduce_kernel<EPI>), dim3(tail * 4), dim3(512), 0, s, p);
+    hipLaunchKernelGGL((gemm_splitk_reduce_kernel<EPI>), dim3(tail * 32), dim3(512), 0, s, p);
   } else {
     if (tail != 0 && tail <= 64 && main_tiles > tail && !force) main_tiles = big_tiles - tail; else tail = 0;
     BL_LAUNCH256(main_tiles);

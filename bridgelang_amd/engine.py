@@ -57,10 +57,10 @@ class OpenVLAEngine:
         tmax = max(d.dino.tokens, d.siglip.tokens)
         dmax = max(d.dino.dim, d.siglip.dim)
         hmax = max(d.dino.mlp_pad, d.siglip.mlp_pad)
-        self.v_col = z(B * 256, (d.patch_k + 63) // 64 * 64)
-        self.v_x, self.v_h, self.v_ao = (z(B * tmax * dmax) for _ in range(3))
-        self.v_qkv = z(B * tmax * 3 * dmax)
-        self.v_mlp = z(B * tmax * hmax)
+        # one private set per tower: the two towers run concurrently on two streams
+        self.vbuf = [dict(col=z(B * 256, (d.patch_k + 63) // 64 * 64), x=z(B * tmax * dmax), h=z(B * tmax * dmax),
+                          ao=z(B * tmax * dmax), qkv=z(B * tmax * 3 * dmax), mlp=z(B * tmax * hmax),
+                          ws=torch.empty(64 << 20, dtype=torch.uint8, device=dev)) for _ in range(2)]
         self.feats = z(B * 256, d.vision_dim)
         self.p1, self.p2 = z(B * 256, 4 * d.vision_dim), z(B * 256, D)
         # llm buffers
@@ -77,7 +77,10 @@ class OpenVLAEngine:
         self.key_mask = torch.ones(B, S, dtype=torch.uint8, device=dev) if use_mask else None
         self.logits_all = z(B * S, d.vocab, dtype=torch.float32) if all_rows else None
 
-        self.vision_ops = self._plan_tower(weights.dino, 0) + self._plan_tower(weights.siglip, d.dino.dim)
+        self.dino_ops = self._plan_tower(weights.dino, 0, self.vbuf[0])
+        self.siglip_ops = self._plan_tower(weights.siglip, d.dino.dim, self.vbuf[1])
+        self.vision_ops = self.dino_ops + self.siglip_ops      # serial order (profiling / single-stream use)
+        self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self.projector_ops = self._plan_projector()
         self.prefill_ops = self._plan_prefill()
         self.decode_ops = [self._plan_decode(t) for t in range(1, n_new)]
@@ -87,37 +90,39 @@ class OpenVLAEngine:
         return ops.gemm(*args, workspace=self.ws, **kw)
 
     # ---- plans ----------------------------------------------------------------------------------------------------
-    def _plan_tower(self, tw: TowerW, feat_col: int) -> List[Op]:
+    def _plan_tower(self, tw: TowerW, feat_col: int, vb: dict) -> List[Op]:
         """timm VisionTransformer up to the tap: K1-K9 of SURVEY §2.4."""
         t, B = tw.dims, self.B
         T, Dm, Hp, hd = t.tokens, t.dim, t.mlp_pad, t.head_dim
         M = B * T
-        x = self.v_x[:M * Dm].view(M, Dm)
-        h = self.v_h[:M * Dm].view(M, Dm)
-        ao = self.v_ao[:M * Dm].view(M, Dm)
-        qkv = self.v_qkv[:M * 3 * Dm].view(M, 3 * Dm)
-        mlp = self.v_mlp[:M * Hp].view(M, Hp)
-        plan = [ops.im2col_patch14(self.pixel_values, t.chan0, self.v_col, run=False)]
+        x = vb["x"][:M * Dm].view(M, Dm)
+        h = vb["h"][:M * Dm].view(M, Dm)
+        ao = vb["ao"][:M * Dm].view(M, Dm)
+        qkv = vb["qkv"][:M * 3 * Dm].view(M, 3 * Dm)
+        mlp = vb["mlp"][:M * Hp].view(M, Hp)
+        v_col = vb["col"]
+        g = lambda *a, **k: ops.gemm(*a, workspace=vb["ws"], **k)     # private split-K scratch per stream
+        plan = [ops.im2col_patch14(self.pixel_values, t.chan0, v_col, run=False)]
         if tw.prefix is not None:
             plan.append(ops.write_prefix_tokens(tw.prefix, x, B, T, run=False))
         # patch-embed GEMM + bias + pos-embed, rows written behind the prefix tokens
-        plan.append(self._g(self.v_col, tw.patch_w, x, EPI_BIAS_RES, bias=tw.patch_b, res=tw.pos, res_row_mod=256,
+        plan.append(g(v_col, tw.patch_w, x, EPI_BIAS_RES, bias=tw.patch_b, res=tw.pos, res_row_mod=256,
                              out_map=(256, T, t.n_prefix), algo_nk=(Dm, self.dims.patch_k), run=False))
         st = (T * 3 * Dm, hd, 3 * Dm)
         for i, b in enumerate(tw.blocks):
             plan.append(ops.layernorm(x, b.norm1_w, b.norm1_b, h, self.dims.ln_eps, run=False))
-            plan.append(self._g(h, b.qkv_w, qkv, EPI_BIAS, bias=b.qkv_b, run=False))
+            plan.append(g(h, b.qkv_w, qkv, EPI_BIAS, bias=b.qkv_b, run=False))
             plan.append(ops.attention(qkv, qkv[:, Dm:], qkv[:, 2 * Dm:], ao, B=B, H=t.heads, Sq=T, Skv=T, head_dim=hd,
                                       q_strides=st, k_strides=st, v_strides=st, o_strides=(T * Dm, hd, Dm),
                                       causal=False, run=False))
-            plan.append(self._g(ao, b.proj_w, x, EPI_BIAS_RES, bias=b.proj_b, scale=b.ls1, res=x, run=False))
+            plan.append(g(ao, b.proj_w, x, EPI_BIAS_RES, bias=b.proj_b, scale=b.ls1, res=x, run=False))
             plan.append(ops.layernorm(x, b.norm2_w, b.norm2_b, h, self.dims.ln_eps, run=False))
-            plan.append(self._g(h, b.fc1_w, mlp, EPI_BIAS_GELU, bias=b.fc1_b, algo_nk=(t.mlp, Dm), run=False))
+            plan.append(g(h, b.fc1_w, mlp, EPI_BIAS_GELU, bias=b.fc1_b, algo_nk=(t.mlp, Dm), run=False))
             if i + 1 < len(tw.blocks):
-                plan.append(self._g(mlp, b.fc2_w, x, EPI_BIAS_RES, bias=b.fc2_b, scale=b.ls2, res=x, algo_nk=(Dm, t.mlp),
+                plan.append(g(mlp, b.fc2_w, x, EPI_BIAS_RES, bias=b.fc2_b, scale=b.ls2, res=x, algo_nk=(Dm, t.mlp),
                                      run=False))
             else:   # tap: drop the prefix tokens and write this tower's channels of the fused feature map
-                plan.append(self._g(mlp, b.fc2_w, self.feats[:, feat_col:feat_col + Dm], EPI_BIAS_RES, bias=b.fc2_b,
+                plan.append(g(mlp, b.fc2_w, self.feats[:, feat_col:feat_col + Dm], EPI_BIAS_RES, bias=b.fc2_b,
                                      scale=b.ls2, res=x, out_map=(T, 256, -t.n_prefix), algo_nk=(Dm, t.mlp), run=False))
         return plan
 
@@ -206,8 +211,28 @@ class OpenVLAEngine:
             out = out + step
         return out
 
+    def run_vision(self) -> None:
+        """The two towers are independent until the projector: DINOv2 on the current stream, SigLIP on a side stream
+        (fork/join with stream waits, which HIP-graph capture records as parallel branches). Their GEMMs often fill only
+        part of the chip (e.g. 264 tiles on 512 slots), so running them side by side recovers the idle CUs."""
+        if self._side is None:
+            ops.run_all(self.vision_ops)
+            return
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            ops.run_all(self.siglip_ops)
+        ops.run_all(self.dino_ops)
+        main.wait_stream(self._side)
+
+    def _run_all_stages(self) -> None:
+        self.run_vision()
+        ops.run_all(self.projector_ops + self.prefill_ops)
+        for step in self.decode_ops:
+            ops.run_all(step)
+
     def run_eager(self) -> None:
-        ops.run_all(self.all_ops())
+        self._run_all_stages()
 
     def capture(self) -> None:
         """Capture the whole action-sequence computation into one HIP graph (after one eager warm-up launch)."""
@@ -215,7 +240,7 @@ class OpenVLAEngine:
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            ops.run_all(self.all_ops())
+            self._run_all_stages()
         self._graph = g
 
     def replay(self) -> None:
