@@ -44,6 +44,8 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--model", default="openvla-7b", choices=["openvla-7b", "openvla-tiny"])
     ap.add_argument("--no-graph", action="store_true", help="replay the op plan eagerly instead of as one HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
+                    help="2 = overlap batch i's decode with batch i+1's vision+prefill (TwoStagePipeline)")
     return ap.parse_args()
 
 
@@ -172,8 +174,19 @@ def main() -> None:
     from bridgelang_amd.engine import OpenVLAEngine
     dims = W.openvla_7b_dims() if args.model == "openvla-7b" else W.tiny_dims()
     w = W.allocate(dims, dev).fill_synthetic(seed=0)
-    eng = OpenVLAEngine(w, args.batch, args.prompt_len)
     ids, pv = make_inputs(args.batch, args.prompt_len, seed=rank, device=dev)
+
+    def timed(replay, steps):
+        """EXACTLY `steps` steps bracketed by barrier + synchronize; elapsed = MAX over ranks."""
+        replicas.fence(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            replay()
+        replicas.fence(dev)
+        return replicas.max_over_ranks(time.perf_counter() - t0, dev)
+
+    # ---- one batch in flight (the latency-oriented predict_action path) ----
+    eng = OpenVLAEngine(w, args.batch, args.prompt_len)
     eng.set_inputs(ids, pv)                      # inputs resident in HBM before the timed region
     if args.no_graph:
         eng.run_eager()
@@ -181,13 +194,19 @@ def main() -> None:
         eng.capture()
     for _ in range(args.warmup):
         eng.replay()
-
-    replicas.fence(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.replay()
-    replicas.fence(dev)
-    elapsed = replicas.max_over_ranks(time.perf_counter() - t0, dev)
+    elapsed_single = timed(eng.replay, args.steps)
+    elapsed = elapsed_single
+    # ---- two batches in flight: batch i's decode overlaps batch i+1's vision + prefill (throughput serving) ----
+    if args.pipeline == 2:
+        from bridgelang_amd.pipeline import TwoStagePipeline
+        pipe = TwoStagePipeline(w, args.batch, args.prompt_len)
+        for e in pipe.engines:
+            e.set_inputs(ids, pv)
+        if not args.no_graph:
+            pipe.capture()
+        for _ in range(max(args.warmup, 2)):     # also fills the pipeline
+            pipe.step()
+        elapsed = timed(pipe.step, args.steps)   # every step completes one batch (submitted one step earlier)
     ids_out = eng.gen_ids.t().cpu()
 
     if rank == 0:
@@ -205,9 +224,11 @@ def main() -> None:
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (f"{dims.name} bf16 inference (BASELINE configs[1]): batch {args.batch} synthetic 224px "
                                     f"frames + {args.prompt_len}-token prompts per GPU, predict_action = vision towers + "
-                                    f"projector + Llama prefill S={eng.S} + 6 cached decode steps, greedy"),
+                                    f"projector + Llama prefill S={eng.S} + 6 cached decode steps, greedy"
+                                    + ("; 2 batches in flight (batch i decode overlaps batch i+1 vision+prefill), one "
+                                       "batch completes per step" if args.pipeline == 2 else "")),
                        "batch_per_gpu": args.batch, "prompt_len": args.prompt_len, "seq_len": eng.S,
-                       "replicas": world, "hip_graph": not args.no_graph},
+                       "replicas": world, "hip_graph": not args.no_graph, "pipeline_depth": args.pipeline},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "kernel": "gemm256_kernel + gemm128_kernel tail (per bl_gemm_bf16 call)", "launches_per_step": gemm["launches"],
@@ -219,6 +240,8 @@ def main() -> None:
                            "per_kernel_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
                            "decode_weight_stream_GBs": (round(skinny["bytes"] / (skinny["ms"] * 1e-3) / 1e9, 1) if skinny else None),
                            "decode_hbm_frac": (round(skinny["bytes"] / (skinny["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if skinny else None),
+                           "one_batch_in_flight": {"value": round(seqs / elapsed_single, 3),
+                                                   "ms_per_step": round(elapsed_single / args.steps * 1e3, 3)},
                            "first_ids": ids_out[0].tolist()},
         }
         if not args.no_cpu_baseline:
