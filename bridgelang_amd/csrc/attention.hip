@@ -8,14 +8,17 @@
 //     query column and 4 keys per 16-key tile: the softmax row reductions are 15 in-lane ops + two cross-lane
 //     shuffles (xor 16, 32), and the fp32 scores are already laid out as the "B" operand of the PV product
 //     O^T = V^T·P^T — no LDS round trip for P (guide §3, "accumulator tile as the next MFMA's operand").
-//   * V is transposed while staging (V^T[d][key] in LDS) so the PV "A" operand is two 8-byte LDS reads per MFMA.
+//   * V is staged row-major exactly like K; the PV "A" operand (V^T) comes from gfx950's transposing LDS read
+//     ds_read_b64_tr_b16 (4 keys x 16 d per 16-lane group), two per MFMA — no transpose pass, no 2-byte LDS writes.
 //   * head_dim 72 is zero-padded in LDS to K=96 for QK^T and to 80 output rows for PV; no padded bytes touch HBM.
 //   * numerics: fp32 scores, fp32 exp/sum, P rounded to bf16 for the PV MFMA, O = bf16(acc / sum) — restated op for
 //     op by oracle/restate.py::attention.
 #include "bl_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace bl_attention_impl {
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
 struct AttnArgs {
   const uint16_t* q; const uint16_t* k; const uint16_t* v; uint16_t* o; const uint8_t* mask;
@@ -37,7 +40,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   static_assert(HD % 8 == 0, "head_dim must be a multiple of 8");
 
   __shared__ __attribute__((aligned(16))) char k_lds[KV_CHUNK * KROW];
-  __shared__ __attribute__((aligned(16))) char vt_lds[DT * 16 * VROW];
+  __shared__ __attribute__((aligned(16))) char v_lds[KV_CHUNK * KROW];   // row-major like K; read transposed (tr_b16)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 
   // zero the LDS padding once (never overwritten by the staging loops)
   for (int i = tid; i < (int)sizeof(k_lds) / 16; i += 256) ((u32x4_t*)k_lds)[i] = (u32x4_t){0u, 0u, 0u, 0u};
-  for (int i = tid; i < (int)sizeof(vt_lds) / 16; i += 256) ((u32x4_t*)vt_lds)[i] = (u32x4_t){0u, 0u, 0u, 0u};
+  for (int i = tid; i < (int)sizeof(v_lds) / 16; i += 256) ((u32x4_t*)v_lds)[i] = (u32x4_t){0u, 0u, 0u, 0u};
 
   // Q fragments ("B" operand): lane holds Q[qrow][8*(lg+4ks) .. +7]
   bf16x8_t qf[KS];
@@ -85,15 +88,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       *(u32x4_t*)(k_lds + key * KROW + ch * 16) = t;
     }
     for (int piece = tid; piece < KV_CHUNK * KCH; piece += 256) {
-      const int key = piece & 63, ch = piece >> 6;   // a wave shares ch → its 64 b16 writes are contiguous
+      const int key = piece / KCH, ch = piece - key * KCH;
       u32x4_t t = {0u, 0u, 0u, 0u};
       if (key0 + key < p.Skv) t = *(const u32x4_t*)(vbase + (long)(key0 + key) * p.v_rs + ch * 8);
-      uint16_t* dst = (uint16_t*)(vt_lds + (ch * 8) * VROW) + key;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        dst[(2 * i) * (VROW / 2)] = (uint16_t)(t[i] & 0xffffu);
-        dst[(2 * i + 1) * (VROW / 2)] = (uint16_t)(t[i] >> 16);
-      }
+      *(u32x4_t*)(v_lds + key * KROW + ch * 16) = t;
     }
     __syncthreads();
 
@@ -152,10 +150,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const char* vp = vt_lds + (dt * 16 + l15) * VROW + (32 * s2 + 4 * lg) * 2;
-        const u32x2_t v0 = *(const u32x2_t*)vp;
-        const u32x2_t v1 = *(const u32x2_t*)(vp + 32);
-        const u32x4_t vv = {v0[0], v0[1], v1[0], v1[1]};
+        // hardware-transposing read: within each 16-lane group, lane 4q+p supplies the address of key row q, d
+        // columns 4p..4p+3 of a 4-key x 16-d block and receives column (lane & 15) of the 4 rows → the V^T fragment.
+        const char* vp = v_lds + (32 * s2 + 4 * lg + (l15 >> 2)) * KROW + (dt * 16 + (l15 & 3) * 4) * 2;
+        const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)vp);
+        const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp + 16 * KROW));
+        const u32x2_t w0 = __builtin_bit_cast(u32x2_t, v0), w1 = __builtin_bit_cast(u32x2_t, v1);
+        const u32x4_t vv = {w0[0], w0[1], w1[0], w1[1]};
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pf[s2], o[dt], 0, 0, 0);
       }
     }
@@ -177,6 +178,164 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         w[0] = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
         w[1] = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
         *(u32x2_t*)(op + d) = w;
+      }
+    }
+  }
+}
+
+// ---- whole-sequence kernel: one workgroup (8 waves) per (batch, head), Skv ≤ 320 ----
+// The OpenVLA sequences are short (256 patches + prompt ≈ 288; ViT 256/261), so K and V of a head fit in LDS at once
+// (≤ 160 KiB): they are staged ONCE (XOR-swizzled 16-byte chunks, no padding), then every wave walks its 16-row query
+// tiles with no further barriers: full score row in registers (≤ 20 key tiles × 4 fp32), exact two-pass softmax (no
+// online rescaling — the oracle's algorithm), P → bf16 → PV with transposing LDS reads. Query tiles are dealt to the 8
+// waves in snake order from the heaviest (causal) tile down, so wave loads differ by < 10 %.
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(512) void attn_seq_kernel(AttnArgs p, int s_pad) {
+  constexpr int HDP = (HD + 31) / 32 * 32;
+  constexpr int KS = HDP / 32;
+  constexpr int KCH = HD / 8;                       // 16-byte chunks per row in HBM
+  constexpr int ROWB = (HD <= 64) ? 128 : 256;      // LDS bytes per row (power of two so the XOR swizzle stays in-row)
+  constexpr int MASK = ROWB / 16 - 1;
+  // V is read with ds_read_b64_tr_b16: a 32-lane half touches 8 keys x 32 B, so V swizzles 32-byte chunk PAIRS
+  // (pair' = pair ^ ((key >> VSH) & VPM)) — with K's per-chunk swizzle adjacent keys would share a slot pair (2-way).
+  constexpr int VSH = (ROWB == 256) ? 0 : 1, VPM = (ROWB == 256) ? 7 : 3;
+  constexpr int DT = (HD + 15) / 16;
+  constexpr int NKT = 20;                           // key tiles held in registers → Skv ≤ 320
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* k_lds = smem;
+  char* v_lds = smem + s_pad * ROWB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const int off = p.Skv - p.Sq;
+  const uint16_t* kbase = p.k + (long)b * p.k_bs + (long)h * p.k_hs;
+  const uint16_t* vbase = p.v + (long)b * p.v_bs + (long)h * p.v_hs;
+  const uint8_t* mrow = p.mask ? p.mask + (long)b * p.mask_bs : nullptr;
+
+  // ---- stage K and V once: chunk c of key row r lives at r*ROWB + ((c ^ (r & MASK)) << 4). One pass over all
+  //      s_pad × CH LDS chunks (pad rows / pad chunks get zeros); loads are issued 6 deep per tensor before the
+  //      LDS writes so a thread pays the global-load latency once per batch, not once per chunk. ----
+  {
+    constexpr int CH = ROWB / 16, UNR = 6;
+    const int npieces = s_pad * CH;
+    for (int base = tid; base < npieces; base += 512 * UNR) {
+      u32x4_t kq[UNR], vq[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int piece = base + u * 512, key = piece / CH, ch = piece - key * CH;
+        kq[u] = (u32x4_t){0u, 0u, 0u, 0u};
+        vq[u] = (u32x4_t){0u, 0u, 0u, 0u};
+        if (piece < npieces && key < p.Skv && ch < KCH) {
+          kq[u] = *(const u32x4_t*)(kbase + (long)key * p.k_rs + ch * 8);
+          vq[u] = *(const u32x4_t*)(vbase + (long)key * p.v_rs + ch * 8);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int piece = base + u * 512, key = piece / CH, ch = piece - key * CH;
+        if (piece < npieces) {
+          *(u32x4_t*)(k_lds + key * ROWB + ((ch ^ (key & MASK)) << 4)) = kq[u];
+          *(u32x4_t*)(v_lds + key * ROWB + (((((ch >> 1) ^ ((key >> VSH) & VPM)) << 1) | (ch & 1)) << 4)) = vq[u];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const int nqt = (p.Sq + 15) >> 4;
+  for (int r = 0; r * 8 < nqt; ++r) {
+    const int idx = r * 8 + ((r & 1) ? 7 - wave : wave);
+    if (idx >= nqt) continue;                       // wave-uniform
+    const int qt = nqt - 1 - idx, q0 = qt * 16, qrow = q0 + l15;
+    int kv_hi = p.Skv;
+    if (CAUSAL) kv_hi = min(p.Skv, q0 + 16 + off);
+
+    bf16x8_t qf[KS];
+    {
+      const uint16_t* qp = p.q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qrow * p.q_rs;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int ch = lg + 4 * ks;
+        u32x4_t t = {0u, 0u, 0u, 0u};
+        if (qrow < p.Sq && ch < KCH) t = *(const u32x4_t*)(qp + ch * 8);
+        qf[ks] = __builtin_bit_cast(bf16x8_t, t);
+      }
+    }
+    // ---- S^T = K · Q^T for every needed key tile ----
+    float sc[NKT][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt * 16 < kv_hi) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8_t kf = *(const bf16x8_t*)(k_lds + (kt * 16 + l15) * ROWB + (((lg + 4 * ks) ^ (l15 & MASK)) << 4));
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int key = kt * 16 + lg * 4 + rr;
+          bool vis = key < p.Skv;
+          if (CAUSAL) vis = vis && (key <= qrow + off);
+          if (mrow) vis = vis && (key < p.Skv ? mrow[key] != 0 : false);
+          sc[kt][rr] = vis ? acc[rr] * p.scale_log2e : -INFINITY;
+          mx = fmaxf(mx, sc[kt][rr]);
+        }
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) sc[kt][rr] = -INFINITY;
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_use = (mx == -INFINITY) ? 0.f : mx;
+    // ---- P = exp2(S - m); O^T += V^T · P^T, 32 keys (two key tiles) per MFMA k-step ----
+    f32x4_t o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float l = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < NKT / 2; ++s2) {
+      if (s2 * 32 < kv_hi) {
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          e[j] = __builtin_amdgcn_exp2f(sc[2 * s2 + (j >> 2)][j & 3] - m_use);
+          l += e[j];
+        }
+        u32x4_t t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = pack2bf(e[2 * j], e[2 * j + 1]);
+        const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, t);
+        const int key = 32 * s2 + 4 * lg + (l15 >> 2);          // +16 for the second read: same (key & MASK)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int pr = dt ^ ((key >> VSH) & VPM);                  // swizzled 32-byte pair (same for key + 16)
+          const char* vp = v_lds + key * ROWB + (((pr << 1) | ((l15 & 3) >> 1)) << 4) + (l15 & 1) * 8;
+          const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)vp);
+          const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp + 16 * ROWB));
+          const u32x2_t w0 = __builtin_bit_cast(u32x2_t, v0), w1 = __builtin_bit_cast(u32x2_t, v1);
+          const u32x4_t vv = {w0[0], w0[1], w1[0], w1[1]};
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pf, o[dt], 0, 0, 0);
+        }
+      }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    if (qrow < p.Sq) {
+      uint16_t* op = p.o + (long)b * p.o_bs + (long)h * p.o_hs + (long)qrow * p.o_rs;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = dt * 16 + lg * 4;
+        if (d < HD) {
+          u32x2_t w;
+          w[0] = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
+          w[1] = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
+          *(u32x2_t*)(op + d) = w;
+        }
       }
     }
   }
@@ -334,13 +493,40 @@ int fill_args(const bl_attn_desc* d, AttnArgs& a) {
 }  // namespace bl_attention_impl
 using namespace bl_attention_impl;
 
+template <int HD, bool CAUSAL>
+int launch_seq(const AttnArgs& a, const bl_attn_desc* d, hipStream_t s) {
+  constexpr int ROWB = (HD <= 64) ? 128 : 256;
+  const int s_pad = (d->Skv + 31) / 32 * 32;
+  const int lds = 2 * s_pad * ROWB;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_seq_kernel<HD, CAUSAL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return BL_E_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_seq_kernel<HD, CAUSAL>), dim3(d->B * d->H), dim3(512), lds, s, a, s_pad);
+  return BL_OK;
+}
+
 extern "C" int bl_attention_bf16(const bl_attn_desc* d, void* stream) {
   AttnArgs a;
   const int rc = fill_args(d, a);
   if (rc != BL_OK) return rc;
   if (d->causal && d->Skv < d->Sq) return BL_E_SHAPE;
-  const dim3 grid((d->Sq + 63) / 64, d->H, d->B), block(256);
   hipStream_t s = (hipStream_t)stream;
+  static const bool chunked_only = getenv("BL_ATTN_CHUNKED") != nullptr;   // A/B aid
+  // short sequences (the whole OpenVLA path): K and V of a head fit in LDS → whole-sequence kernel
+  if (d->Skv <= 320 && d->Sq <= 320 && !chunked_only) {
+    int r = BL_E_SHAPE;
+#define BL_SEQ_CASE(HD) case HD: r = d->causal ? launch_seq<HD, true>(a, d, s) : launch_seq<HD, false>(a, d, s); break;
+    switch (d->head_dim) { BL_SEQ_CASE(64) BL_SEQ_CASE(72) BL_SEQ_CASE(128) default: return BL_E_SHAPE; }
+#undef BL_SEQ_CASE
+    if (r != BL_OK) return r;
+    BL_CHECK_LAUNCH();
+    return BL_OK;
+  }
+  const dim3 grid((d->Sq + 63) / 64, d->H, d->B), block(256);
 #define BL_ATTN_CASE(HD)                                                                       \
   case HD:                                                                                     \
     if (d->causal) hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, block, 0, s, a);      \
