@@ -30,10 +30,13 @@ def rope_tables(head_dim: int, max_pos: int, theta: float, device) -> tuple:
 
 class OpenVLAEngine:
     def __init__(self, weights: VLAWeights, batch: int, prompt_len: int, n_new: int = 7, all_rows: bool = False,
-                 use_mask: bool = False):
+                 use_mask: bool = False, splitk: bool = False):
         """all_rows=True builds the training/eval-style forward instead of generation: logits for every position
         (`logits_all` [B*S, vocab] fp32) and no decode steps. use_mask=True threads a [B, S] uint8 key-padding mask
-        (`key_mask`, 1 = attend) through the Llama attention (modeling_prismatic.py:387-390)."""
+        (`key_mask`, 1 = attend) through the Llama attention (modeling_prismatic.py:387-390). splitk=True lets
+        bl_gemm_bf16 split the K range of the last, partially filled round of tiles (≈ +2 % throughput at 7B) — OFF by
+        default because those rows then sum in a different fp32 order than the rest, so a sequence's result would depend
+        on its batch slot (it breaks "batch-B ≡ B × batch-1 bit for bit", tests/test_full_size_gpu.py)."""
         self.w, self.dims = weights, weights.dims
         d = self.dims
         if all_rows:
@@ -60,7 +63,7 @@ class OpenVLAEngine:
         # one private set per tower: the two towers run concurrently on two streams
         self.vbuf = [dict(col=z(B * 256, (d.patch_k + 63) // 64 * 64), x=z(B * tmax * dmax), h=z(B * tmax * dmax),
                           ao=z(B * tmax * dmax), qkv=z(B * tmax * 3 * dmax), mlp=z(B * tmax * hmax),
-                          ws=torch.empty(64 << 20, dtype=torch.uint8, device=dev)) for _ in range(2)]
+                          ws=None) for _ in range(2)]   # ViT GEMMs never reach the split-K regime (K <= 4352)
         self.feats = z(B * 256, d.vision_dim)
         self.p1, self.p2 = z(B * 256, 4 * d.vision_dim), z(B * 256, D)
         # llm buffers
@@ -73,7 +76,7 @@ class OpenVLAEngine:
         self.xd, self.hd, self.aod = z(B, D), z(B, D), z(B, D)
         self.qkvd, self.actd = z(B, 3 * D), z(B, I)
         self.cos, self.sin = rope_tables(d.head_dim, d.max_pos, d.rope_theta, dev)
-        self.ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)   # split-K scratch shared by all GEMMs (one stream)
+        self.ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev) if splitk else None   # split-K scratch (opt-in)
         self.key_mask = torch.ones(B, S, dtype=torch.uint8, device=dev) if use_mask else None
         self.logits_all = z(B * S, d.vocab, dtype=torch.float32) if all_rows else None
 

@@ -138,6 +138,23 @@ def test_gemm_splitk_tail(dev, M, N, K, epi):
     close_bf16(out, out2.cpu().float(), "split-K vs 128-tail dispatch", min_exact=0.97)
 
 
+@pytest.mark.parametrize("N,K", [(4096, 1024), (1024, 2048)])
+def test_gemm_rows_independent_of_batch(dev, N, K):
+    """Batch invariance at op level: a row's output must be bit-identical whether it is computed alone (M = 288 → the
+    128x128 kernel) or inside a 16x larger problem (the 256x256 pipelined kernel, whole rounds + 128-tile tail), for
+    every position in the big problem. (No workspace → no split-K, which is the one path that would break this.)"""
+    from bridgelang_amd import ops
+    S, B = 288, 16
+    a, w = rand_bf16((B * S, K), 1), rand_bf16((N, K), 2, 0.05)
+    A, W = dv(a, dev), pk(w, dev)
+    big = torch.empty(B * S, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(A, W, big, ops.EPI_NONE)
+    for b in (0, 7, 14, 15):
+        one = torch.empty(S, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(A[b * S:(b + 1) * S], W, one, ops.EPI_NONE)
+        assert torch.equal(one, big[b * S:(b + 1) * S]), f"sequence {b}"
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 192, 128), (522, 256, 1088), (1305, 768, 448)])
 def test_gemm_residual_layerscale_swiglu(dev, M, N, K):
     from bridgelang_amd import ops
