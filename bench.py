@@ -217,6 +217,10 @@ def main() -> None:
         achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
         skinny = prof.get("bl_gemm_skinny_bf16")
         kern_ms = sum(a["ms"] for a in prof.values())
+        traffic = None      # HBM bytes per GEMM call from the committed PMC passes (bench.py cannot run rocprofv3 itself)
+        pmc = ROOT / "profiles" / "pmc_r01" / "gemm_traffic.json"
+        if pmc.exists() and args.model == "openvla-7b" and args.batch == 16 and args.prompt_len == 32:
+            traffic = round(json.loads(pmc.read_text())["avg_hbm_bytes_per_call_llama_layer"])
         line = {
             "metric": "action-seqs/sec (7-DoF, 224px) openvla-7b bf16", "value": round(value, 3), "unit": "action-seqs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -230,7 +234,8 @@ def main() -> None:
                        "batch_per_gpu": args.batch, "prompt_len": args.prompt_len, "seq_len": eng.S,
                        "replicas": world, "hip_graph": not args.no_graph, "pipeline_depth": args.pipeline},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_note": "avg HBM+Infinity-Cache bytes per bl_gemm_bf16 call over the 4 Llama prefill GEMMs, separate --pmc passes (profiles/pmc_r01/gemm_traffic.json)",
                          "kernel": "gemm256_kernel + gemm128_kernel tail (per bl_gemm_bf16 call)", "launches_per_step": gemm["launches"],
                          "avg_launch_us": round(gemm["ms"] * 1e3 / gemm["launches"], 2),
                          "algorithmic_gflop_per_launch": round(gemm["flops"] / gemm["launches"] / 1e9, 3)},
