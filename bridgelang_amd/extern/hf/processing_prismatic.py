@@ -1,0 +1,85 @@
+"""Host-side preprocessing for the fused DINOv2 + SigLIP backbone: PIL image → `pixel_values [6, 224, 224]`.
+
+Mirrors `PrismaticImageProcessor.apply_transform` / `PrismaticProcessor.__call__`
+(prismatic/extern/hf/processing_prismatic.py:128-145,187-216) for the "resize-naive" strategy OpenVLA uses: per backbone
+resize straight to 224×224 with PIL bicubic (what torchvision's functional `resize` does for PIL inputs), centre crop
+(identity at 224), `to_tensor` (uint8 / 255, CHW fp32), normalise with the backbone's own mean/std (DINOv2: ImageNet;
+SigLIP: 0.5/0.5 — timm data_cfg values recorded at convert_openvla_weights_to_hf.py:193-197), stack on the channel axis.
+Runs on the CPU exactly like the reference (a few hundred µs per frame); the device path starts at `pixel_values`.
+torchvision is not installed here, so bit-exactness against it is unpinned; the arithmetic is the same torch ops.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+from PIL import Image
+
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+HALF = (0.5, 0.5, 0.5)
+
+
+class PrismaticImageProcessor:
+    model_input_names = ["pixel_values"]
+
+    def __init__(self, use_fused_vision_backbone: bool = True, image_resize_strategy: str = "resize-naive",
+                 input_sizes: Optional[List[Tuple[int, int, int]]] = None,
+                 means: Optional[Sequence[Sequence[float]]] = None, stds: Optional[Sequence[Sequence[float]]] = None,
+                 **_: Any) -> None:
+        if image_resize_strategy != "resize-naive":
+            raise ValueError(f"Image resize strategy `{image_resize_strategy}` is not supported on this path")
+        self.use_fused_vision_backbone, self.image_resize_strategy = use_fused_vision_backbone, image_resize_strategy
+        n = 2 if use_fused_vision_backbone else 1
+        self.input_sizes = input_sizes if input_sizes is not None else [(3, 224, 224)] * n
+        self.means = [tuple(m) for m in (means if means is not None else [IMAGENET_MEAN, HALF][:n])]
+        self.stds = [tuple(s) for s in (stds if stds is not None else [IMAGENET_STD, HALF][:n])]
+
+    def apply_transform(self, img: Image.Image) -> torch.Tensor:
+        planes = []
+        for (_, h, w), mean, std in zip(self.input_sizes, self.means, self.stds):
+            im = img.resize((w, h), Image.BICUBIC)                                    # TVF.resize on a PIL image
+            t = torch.from_numpy(np.asarray(im, dtype=np.uint8).copy()).permute(2, 0, 1).contiguous()
+            t = t.to(torch.float32).div(255)                                          # TVF.to_tensor
+            m = torch.tensor(mean, dtype=torch.float32).view(3, 1, 1)
+            s = torch.tensor(std, dtype=torch.float32).view(3, 1, 1)
+            planes.append(t.sub_(m).div_(s))                                          # TVF.normalize
+        return torch.vstack(planes)
+
+    def preprocess(self, images: Union[Image.Image, List[Image.Image]], return_tensors: Optional[str] = None,
+                   **_: Any) -> Dict[str, Any]:
+        if not isinstance(images, list):
+            images = [images]
+        pv = torch.stack([self.apply_transform(im.convert("RGB")) for im in images])
+        return {"pixel_values": pv if return_tensors == "pt" else pv.numpy()}
+
+    __call__ = preprocess
+
+
+class ProcessorOutput(dict):
+    """dict with attribute access and `.to(device, dtype=…)` (floating tensors only are cast), like HF BatchFeature."""
+    __getattr__ = dict.__getitem__
+
+    def to(self, device=None, dtype: Optional[torch.dtype] = None) -> "ProcessorOutput":
+        out = ProcessorOutput()
+        for k, v in self.items():
+            if torch.is_tensor(v):
+                v = v.to(device=device, dtype=dtype if (dtype is not None and v.is_floating_point()) else None)
+            out[k] = v
+        return out
+
+
+class PrismaticProcessor:
+    """`processor(text, images)` → input_ids, attention_mask, pixel_values (reference :187-216)."""
+
+    def __init__(self, image_processor: Optional[PrismaticImageProcessor] = None, tokenizer: Any = None) -> None:
+        self.image_processor = image_processor if image_processor is not None else PrismaticImageProcessor()
+        self.tokenizer = tokenizer
+
+    def __call__(self, text: Union[str, List[str]], images: Union[Image.Image, List[Image.Image]],
+                 return_tensors: str = "pt", **tok_kwargs: Any) -> ProcessorOutput:
+        pv = self.image_processor(images, return_tensors=return_tensors)["pixel_values"]
+        enc = self.tokenizer(text, return_tensors=return_tensors, **tok_kwargs)
+        if pv.shape[0] != enc["input_ids"].shape[0]:
+            raise ValueError("Batch is malformed; expected same number of images and text inputs!")
+        return ProcessorOutput(input_ids=enc["input_ids"], attention_mask=enc["attention_mask"], pixel_values=pv)
