@@ -91,3 +91,40 @@ def test_predict_action_matches_oracle(model, dev):
     ids3, pv3 = ids.repeat(3, 1), pv.repeat(3, 1, 1, 1)
     got3 = m.predict_action(ids3.to(dev), unnorm_key="bridge_orig", pixel_values=pv3.to(dev))
     assert got3.shape == (3, 7) and np.array_equal(got3[0], got) and np.array_equal(got3[2], got)
+
+
+def test_training_step_metrics(model, dev):
+    """forward(labels) + action accuracy / L1 (base_strategy.py:314-329) vs the same quantities from the oracle."""
+    from bridgelang_amd.training.metrics import vla_action_metrics
+    from bridgelang_amd.vla.action_tokenizer import ActionTokenizer
+
+    class Tok:
+        vocab_size = 32000
+    at = ActionTokenizer(Tok())
+    dims, m, oracle, _ = model
+    B, L = 2, 20
+    ids, pv = inputs(B, L, 9)
+    g = np.random.RandomState(0)
+    for b in range(B):                                        # 7 action tokens + EOS at the end, as RLDSBatchTransform builds
+        ids[b, -8:-1] = torch.from_numpy(at.encode_ids(g.rand(7) * 2 - 1))
+        ids[b, -1] = 2
+    labels = torch.full((B, L), -100)
+    labels[:, -8:] = ids[:, -8:]
+    out = m.forward(input_ids=ids.to(dev), pixel_values=pv.to(dev), labels=labels.to(dev))
+    got = vla_action_metrics(out.logits, labels, at, num_patches=256)
+    logits_ref, _, _ = oracle.prefill(ids, pv)
+    preds = logits_ref[:, 256:-1].argmax(2)
+    gt = labels[:, 1:]
+    mask = gt > at.action_token_begin_idx
+    assert got["n_action_tokens"] == int(mask.sum()) == 14
+    acc_ref = float(((preds == gt) & mask).sum()) / int(mask.sum())
+    l1_ref = float(np.abs(at.decode_token_ids_to_actions(preds[mask].numpy()) - at.decode_token_ids_to_actions(gt[mask].numpy())).mean())
+    # device ids may differ from the oracle's only at bf16 near-ties; the synthetic model predicts no action token, so
+    # both accuracies are 0 and both L1s are driven by the same clipped bin
+    print(f"\nmetrics: device {got} | oracle acc {acc_ref} l1 {l1_ref:.4f}")
+    assert abs(got["action_accuracy"] - acc_ref) <= 1.0 / 14 + 1e-9
+    assert abs(got["l1_loss"] - l1_ref) <= 0.15
+    dev_preds = torch.empty(B * (L + 256), dtype=torch.int64, device=dev)
+    from bridgelang_amd import ops
+    ops.argmax(out.logits.reshape(-1, dims.vocab), dev_preds)
+    assert torch.equal(dev_preds.cpu().view(B, -1), out.logits.cpu().argmax(-1))       # bit-exact argmax incl. ties
