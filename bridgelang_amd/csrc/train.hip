@@ -1,0 +1,469 @@
+// train.hip — backward / optimizer kernels of the VLA training step (prismatic/training/strategies/base_strategy.py:284-366,
+// fsdp.py:190-246): everything around the GEMMs. All HBM-bound: 16-byte vector accesses, one wave per row for the row-wise
+// ops, fp32 math on bf16 tensors, deterministic reductions (per-block partials + a second pass; no float atomics except
+// the sparse embedding scatter).
+//
+// Gradient conventions: activations and their gradients are bf16; parameter gradients, AdamW moments and master weights
+// are fp32 (the reference trains fp32 masters under bf16 autocast with fp32 gradient reduction: train.py:156-157,
+// fsdp.py:140-146). Roundings of the forward (`bf16(...)`) are treated as identity in the backward, exactly as autograd
+// treats a dtype cast.
+#include "bl_common.h"
+#include <math.h>
+
+namespace bl_train_impl {
+
+__device__ __forceinline__ void unpack8(const u32x4_t q, float* v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = bflo(q[i]); v[2 * i + 1] = bfhi(q[i]); }
+}
+__device__ __forceinline__ u32x4_t pack8(const float* v) {
+  u32x4_t q;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+  return q;
+}
+
+// ---- cross-entropy backward: dlogits = (softmax(logits) - onehot(target)) / n_valid, 0 on ignored rows ----
+__global__ __launch_bounds__(256) void ce_backward_kernel(const float* logits, long ld, int n, const int64_t* targets,
+                                                          long ignore_index, const float* mean_and_count,
+                                                          uint16_t* dlogits, long ldd) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const long tgt = targets[row];
+  uint16_t* dr = dlogits + (long)row * ldd;
+  if (tgt == ignore_index) {
+    for (int i = threadIdx.x * 8; i < n; i += 2048) *(u32x4_t*)(dr + i) = (u32x4_t){0u, 0u, 0u, 0u};
+    return;
+  }
+  const float* lr = logits + (long)row * ld;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x * 4; i < n; i += 1024) {
+    const f32x4_t q = *(const f32x4_t*)(lr + i);
+    mx = fmaxf(fmaxf(mx, fmaxf(q[0], q[1])), fmaxf(q[2], q[3]));
+  }
+  mx = wave_max(mx);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int i = threadIdx.x * 4; i < n; i += 1024) {
+    const f32x4_t q = *(const f32x4_t*)(lr + i);
+    s += expf(q[0] - mx) + expf(q[1] - mx) + expf(q[2] - mx) + expf(q[3] - mx);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[wave] = s;
+  __syncthreads();
+  const float inv = 1.0f / ((red[0] + red[1] + red[2] + red[3]) * mean_and_count[1]);   // 1 / (sum_exp * n_valid)
+  const float inv_cnt = 1.0f / mean_and_count[1];
+  for (int i = threadIdx.x * 8; i < n; i += 2048) {
+    const f32x4_t a = *(const f32x4_t*)(lr + i), b = *(const f32x4_t*)(lr + i + 4);
+    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = expf(v[e] - mx) * inv - ((long)(i + e) == tgt ? inv_cnt : 0.f);
+    *(u32x4_t*)(dr + i) = pack8(v);
+  }
+}
+
+// ---- RMSNorm backward (+ residual-stream gradient add), one wave per row ----
+//   g = w ⊙ dy;  x̂ = x·rstd;  dx = rstd·(g − x̂·mean(g ⊙ x̂)) [+ dres];  dw partial[block][j] = Σ_rows dy_j · bf16(x̂_j)
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const uint16_t* x, long ldx, const uint16_t* w,
+                                                          const uint16_t* dy, long lddy, const uint16_t* dres,
+                                                          long lddres, uint16_t* dx, long lddx, float* dw_partial,
+                                                          int rows, int dim, float eps, int rows_per_block) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = dim >> 3;
+  float dwacc[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dwacc[c][i] = 0.f;
+  const int r0 = blockIdx.x * rows_per_block;
+  for (int rr = wave; rr < rows_per_block; rr += 4) {
+    const int row = r0 + rr;
+    if (row >= rows) break;
+    float xv[NCH][8], gv[NCH][8], dyv[NCH][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = c * 64 + lane;
+      const bool in = ch < nchunk;
+      u32x4_t qx = {0u, 0u, 0u, 0u}, qd = qx, qw = qx;
+      if (in) {
+        qx = *(const u32x4_t*)(x + (long)row * ldx + ch * 8);
+        qd = *(const u32x4_t*)(dy + (long)row * lddy + ch * 8);
+        qw = *(const u32x4_t*)(w + ch * 8);
+      }
+      float wv[8];
+      unpack8(qx, xv[c]); unpack8(qd, dyv[c]); unpack8(qw, wv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { gv[c][i] = wv[i] * dyv[c][i]; ss += xv[c][i] * xv[c][i]; }
+    }
+    ss = wave_sum(ss);
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / (float)dim) + eps);
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dot += gv[c][i] * xv[c][i] * rstd;
+    dot = wave_sum(dot) * (1.0f / (float)dim);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = c * 64 + lane;
+      if (ch >= nchunk) continue;
+      float o[8], dr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (dres) unpack8(*(const u32x4_t*)(dres + (long)row * lddres + ch * 8), dr);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xh = xv[c][i] * rstd;
+        o[i] = rstd * (gv[c][i] - xh * dot) + dr[i];
+        dwacc[c][i] += dyv[c][i] * rbf(xh);
+      }
+      *(u32x4_t*)(dx + (long)row * lddx + ch * 8) = pack8(o);
+    }
+  }
+  // per-block dw partial: the 4 waves of the block own disjoint rows → sum them through LDS, lane-major
+  __shared__ float sh[4][64 * 8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sh[wave][lane * 8 + i] = dwacc[c][i];
+    __syncthreads();
+    if (wave == 0) {
+      const int ch = c * 64 + lane;
+      if (ch < nchunk) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          dw_partial[(long)blockIdx.x * dim + ch * 8 + i] = sh[0][lane * 8 + i] + sh[1][lane * 8 + i] + sh[2][lane * 8 + i] + sh[3][lane * 8 + i];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// out[j] = Σ_b partial[b][j]   (fixed order → deterministic)
+__global__ void reduce_partials_kernel(const float* partial, int nblocks, int dim, float* out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= dim) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * dim + j];
+  out[j] = s;
+}
+
+// column sums of a bf16 matrix [rows, cols] → per-block partials (bias gradients)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const uint16_t* a, long lda, int rows, int cols,
+                                                             int rows_per_block, float* partial) {
+  const int col8 = (blockIdx.y * 256 + threadIdx.x) * 8;
+  if (col8 >= cols) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (int r = r0; r < r1; ++r) {
+    float v[8];
+    unpack8(*(const u32x4_t*)(a + (long)r * lda + col8), v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += v[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) partial[(long)blockIdx.x * cols + col8 + i] = acc[i];
+}
+
+// ---- SwiGLU on an interleaved gate/up buffer gu [M, 2I] (col 2j = gate_j, 2j+1 = up_j) ----
+__global__ void swiglu_fwd_kernel(const uint16_t* gu, long ldg, uint16_t* act, long lda, long rows, int inter) {
+  const long total = rows * (inter >> 2);
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long r = t / (inter >> 2);
+    const int j = (int)(t - r * (inter >> 2)) * 4;
+    float v[8];
+    unpack8(*(const u32x4_t*)(gu + r * ldg + 2 * j), v);
+    u32x2_t o;
+    o[0] = pack2bf(rbf(silu_f(v[0])) * v[1], rbf(silu_f(v[2])) * v[3]);
+    o[1] = pack2bf(rbf(silu_f(v[4])) * v[5], rbf(silu_f(v[6])) * v[7]);
+    *(u32x2_t*)(act + r * lda + j) = o;
+  }
+}
+__global__ void swiglu_bwd_kernel(const uint16_t* gu, long ldg, const uint16_t* dact, long ldd, uint16_t* dgu,
+                                  long ldo, long rows, int inter) {
+  const long total = rows * (inter >> 2);
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long r = t / (inter >> 2);
+    const int j = (int)(t - r * (inter >> 2)) * 4;
+    float v[8], o[8];
+    unpack8(*(const u32x4_t*)(gu + r * ldg + 2 * j), v);
+    const u32x2_t dq = *(const u32x2_t*)(dact + r * ldd + j);
+    const float da[4] = {bflo(dq[0]), bfhi(dq[0]), bflo(dq[1]), bfhi(dq[1])};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g = v[2 * e], u = v[2 * e + 1];
+      const float sg = 1.0f / (1.0f + expf(-g));
+      o[2 * e] = da[e] * u * (sg * (1.0f + g * (1.0f - sg)));      // d gate
+      o[2 * e + 1] = da[e] * rbf(g * sg);                            // d up = dact · bf16(silu(gate))
+    }
+    *(u32x4_t*)(dgu + r * ldo + 2 * j) = pack8(o);
+  }
+}
+
+// ---- exact-erf GELU forward / backward (projector; training keeps the pre-activation) ----
+__global__ void gelu_fwd_kernel(const uint16_t* x, uint16_t* y, long n8) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    unpack8(*(const u32x4_t*)(x + t * 8), v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i]);
+    *(u32x4_t*)(y + t * 8) = pack8(v);
+  }
+}
+__global__ void gelu_bwd_kernel(const uint16_t* x, const uint16_t* dy, uint16_t* dx, long n8) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += (long)gridDim.x * blockDim.x) {
+    float v[8], d[8];
+    unpack8(*(const u32x4_t*)(x + t * 8), v);
+    unpack8(*(const u32x4_t*)(dy + t * 8), d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      d[i] *= 0.5f * (1.0f + erff(v[i] * 0.70710678118654752440f)) + v[i] * 0.39894228040143267794f * expf(-0.5f * v[i] * v[i]);
+    *(u32x4_t*)(dx + t * 8) = pack8(d);
+  }
+}
+
+// ---- RoPE backward on the q and k thirds of a fused dqkv buffer [B*S, 3*H*hd] (transpose of the rotation) ----
+__global__ void rope_bwd_kernel(uint16_t* dqkv, int B, int S, int H, int hd, const uint16_t* cos_tab,
+                                const uint16_t* sin_tab, int pos0) {
+  const int half = hd >> 1, cpr = half >> 3;
+  const long total = (long)B * S * H * cpr * 2;
+  const long D = (long)H * hd;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int part = (int)(i & 1);
+    const long ii = i >> 1;
+    const int ch = (int)(ii % cpr), h = (int)((ii / cpr) % H);
+    const long tok = ii / ((long)cpr * H);
+    const int pos = pos0 + (int)(tok % S);
+    float c[8], s[8], d1[8], d2[8], o1[8], o2[8];
+    unpack8(*(const u32x4_t*)(cos_tab + (long)pos * half + ch * 8), c);
+    unpack8(*(const u32x4_t*)(sin_tab + (long)pos * half + ch * 8), s);
+    uint16_t* p = dqkv + tok * 3 * D + part * D + (long)h * hd + ch * 8;
+    unpack8(*(const u32x4_t*)p, d1);
+    unpack8(*(const u32x4_t*)(p + half), d2);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o1[e] = d1[e] * c[e] + d2[e] * s[e]; o2[e] = d2[e] * c[e] - d1[e] * s[e]; }
+    *(u32x4_t*)p = pack8(o1);
+    *(u32x4_t*)(p + half) = pack8(o2);
+  }
+}
+
+// ---- transpose bf16 [rows, cols] → [cols, rows_pad] (rows_pad ≥ rows, pad zero-filled): feeds the wgrad GEMMs ----
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const uint16_t* in, long ldi, int rows, int cols,
+                                                            uint16_t* out, long ldo, int rows_pad) {
+  __shared__ uint16_t tile[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < rows && c0 + c < cols) ? in[(long)(r0 + r) * ldi + c0 + c] : (uint16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (c0 + c < cols && r0 + r < rows_pad) out[(long)(c0 + c) * ldo + r0 + r] = tile[r][c];
+  }
+}
+
+// ---- optimizer ----
+// sum of squares of an fp32 tensor → per-block partials (grad-norm)
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, long n, float* partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// total norm + clip coefficient (torch.nn.utils.clip_grad_norm_: coef = clamp(max_norm / (norm + 1e-6), max = 1))
+__global__ void clip_coef_kernel(const float* partial, int n, float max_norm, float* out_norm_coef) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += (double)partial[i];
+  const float norm = (float)sqrt(s);
+  out_norm_coef[0] = norm;
+  out_norm_coef[1] = fminf(1.0f, max_norm / (norm + 1e-6f));
+}
+// torch.optim.AdamW single-tensor step, fp32 master + moments, optional bf16 copy of the new weights
+__global__ void adamw_kernel(float* p, float* m, float* v, const float* g, const float* norm_coef, long n, float lr,
+                             float beta1, float beta2, float eps, float wd, float bias_c1, float bias_c2_sqrt,
+                             uint16_t* p_bf16) {
+  const float coef = norm_coef ? norm_coef[1] : 1.0f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bias_c2_sqrt + eps;
+    pi -= (lr / bias_c1) * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (p_bf16) p_bf16[i] = f2bf(pi);
+  }
+}
+
+// ---- embedding backward: dW[ids[b,j]] += dx[b, row(j)] for the text positions of the multimodal splice ----
+__global__ void embed_bwd_kernel(const int64_t* ids, int B, int L, const uint16_t* dx, int dim, int n_patches, float* dw) {
+  const int cpr = dim >> 3;
+  const long total = (long)B * L * cpr;
+  const int S = L + n_patches;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cpr);
+    const long t = i / cpr;
+    const int j = (int)(t % L), b = (int)(t / L);
+    const long id = ids[(long)b * L + j];
+    const int row = (j == 0) ? 0 : j + n_patches;
+    float v[8];
+    unpack8(*(const u32x4_t*)(dx + ((long)b * S + row) * dim + ch * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(dw + id * dim + ch * 8 + e, v[e]);
+  }
+}
+
+inline int grid_for(long total, int block) {
+  long g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace bl_train_impl
+using namespace bl_train_impl;
+
+extern "C" int bl_cross_entropy_backward_f32(const float* logits, int64_t ld, int32_t rows, int32_t n,
+                                             const int64_t* targets, int64_t ignore_index, const float* mean_and_count,
+                                             bl_bf16* dlogits, int64_t ldd, void* stream) {
+  if (!logits || !targets || !mean_and_count || !dlogits) return BL_E_ARG;
+  if (rows <= 0 || n <= 0 || (n % 8) || (ld % 4) || (ldd % 8)) return BL_E_SHAPE;
+  if (!bl_aligned16(logits) || !bl_aligned16(dlogits)) return BL_E_ALIGN;
+  hipLaunchKernelGGL(ce_backward_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, n, targets,
+                     (long)ignore_index, mean_and_count, dlogits, (long)ldd);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_rmsnorm_backward_bf16(const bl_bf16* x, int64_t ldx, const bl_bf16* w, const bl_bf16* dy, int64_t lddy,
+                                        const bl_bf16* dres, int64_t lddres, bl_bf16* dx, int64_t lddx, float* dw,
+                                        float* partial_ws, int64_t partial_ws_floats, int32_t rows, int32_t dim,
+                                        float eps, void* stream) {
+  if (!x || !w || !dy || !dx || !dw || !partial_ws) return BL_E_ARG;
+  if (rows <= 0 || dim <= 0 || (dim % 8) || dim > 64 * 8 * 10) return BL_E_SHAPE;
+  if ((ldx % 8) || (lddy % 8) || (lddx % 8) || (dres && (lddres % 8))) return BL_E_ALIGN;
+  const int rpb = 64, nblk = (rows + rpb - 1) / rpb;
+  if (partial_ws_floats < (int64_t)nblk * dim) return BL_E_SHAPE;
+  const int nch = (dim / 8 + 63) / 64;
+  hipStream_t s = (hipStream_t)stream;
+#define BL_CASE(N) case N: hipLaunchKernelGGL((rmsnorm_bwd_kernel<N>), dim3(nblk), dim3(256), 0, s, x, (long)ldx, w, dy, \
+    (long)lddy, dres, (long)lddres, dx, (long)lddx, partial_ws, rows, dim, eps, rpb); break;
+  switch (nch) { BL_CASE(1) BL_CASE(2) BL_CASE(3) BL_CASE(4) BL_CASE(5) BL_CASE(6) BL_CASE(7) BL_CASE(8) BL_CASE(9) BL_CASE(10)
+    default: return BL_E_SHAPE; }
+#undef BL_CASE
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((dim + 255) / 256), dim3(256), 0, s, partial_ws, nblk, dim, dw);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_colsum_bf16(const bl_bf16* a, int64_t lda, int32_t rows, int32_t cols, float* out, float* partial_ws,
+                              int64_t partial_ws_floats, void* stream) {
+  if (!a || !out || !partial_ws) return BL_E_ARG;
+  if (rows <= 0 || cols <= 0 || (cols % 8) || (lda % 8)) return BL_E_SHAPE;
+  const int rpb = 256, nblk = (rows + rpb - 1) / rpb;
+  if (partial_ws_floats < (int64_t)nblk * cols) return BL_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, (cols / 8 + 255) / 256), dim3(256), 0, s, a, (long)lda, rows, cols,
+                     rpb, partial_ws);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, partial_ws, nblk, cols, out);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_swiglu_bf16(const bl_bf16* gu, int64_t ldg, bl_bf16* act, int64_t lda, int64_t rows, int32_t inter,
+                              void* stream) {
+  if (!gu || !act) return BL_E_ARG;
+  if (rows <= 0 || inter <= 0 || (inter % 4) || (ldg % 8) || (lda % 4)) return BL_E_SHAPE;
+  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(rows * (inter / 4), 256)), dim3(256), 0, (hipStream_t)stream, gu,
+                     (long)ldg, act, (long)lda, (long)rows, inter);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+extern "C" int bl_swiglu_backward_bf16(const bl_bf16* gu, int64_t ldg, const bl_bf16* dact, int64_t ldd, bl_bf16* dgu,
+                                       int64_t ldo, int64_t rows, int32_t inter, void* stream) {
+  if (!gu || !dact || !dgu) return BL_E_ARG;
+  if (rows <= 0 || inter <= 0 || (inter % 4) || (ldg % 8) || (ldd % 4) || (ldo % 8)) return BL_E_SHAPE;
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (inter / 4), 256)), dim3(256), 0, (hipStream_t)stream, gu,
+                     (long)ldg, dact, (long)ldd, dgu, (long)ldo, (long)rows, inter);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_gelu_bf16(const bl_bf16* x, bl_bf16* y, int64_t n, void* stream) {
+  if (!x || !y) return BL_E_ARG;
+  if (n <= 0 || (n % 8)) return BL_E_SHAPE;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, y, (long)(n / 8));
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+extern "C" int bl_gelu_backward_bf16(const bl_bf16* x, const bl_bf16* dy, bl_bf16* dx, int64_t n, void* stream) {
+  if (!x || !dy || !dx) return BL_E_ARG;
+  if (n <= 0 || (n % 8)) return BL_E_SHAPE;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (long)(n / 8));
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_rope_backward_bf16(bl_bf16* dqkv, int32_t B, int32_t S, int32_t H, int32_t hd, const bl_bf16* cos_tab,
+                                     const bl_bf16* sin_tab, int32_t pos0, void* stream) {
+  if (!dqkv || !cos_tab || !sin_tab) return BL_E_ARG;
+  if (B <= 0 || S <= 0 || H <= 0 || hd <= 0 || (hd % 16) || pos0 < 0) return BL_E_SHAPE;
+  const long total = (long)B * S * H * (hd / 16) * 2;
+  hipLaunchKernelGGL(rope_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, dqkv, B, S, H, hd,
+                     cos_tab, sin_tab, pos0);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_transpose_pad_bf16(const bl_bf16* in, int64_t ldi, int32_t rows, int32_t cols, bl_bf16* out,
+                                     int64_t ldo, int32_t rows_pad, void* stream) {
+  if (!in || !out) return BL_E_ARG;
+  if (rows <= 0 || cols <= 0 || rows_pad < rows || ldo < rows_pad) return BL_E_SHAPE;
+  hipLaunchKernelGGL(transpose_pad_kernel, dim3((rows_pad + 63) / 64, (cols + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     in, (long)ldi, rows, cols, out, (long)ldo, rows_pad);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_sumsq_partial_f32(const float* g, int64_t n, float* partial, int32_t nblocks, void* stream) {
+  if (!g || !partial) return BL_E_ARG;
+  if (n <= 0 || nblocks <= 0 || nblocks > 1024) return BL_E_SHAPE;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, g, (long)n, partial);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+extern "C" int bl_clip_coef_f32(const float* partial, int32_t n, float max_norm, float* out_norm_coef, void* stream) {
+  if (!partial || !out_norm_coef) return BL_E_ARG;
+  if (n <= 0) return BL_E_SHAPE;
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, n, max_norm, out_norm_coef);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+extern "C" int bl_adamw_f32(float* p, float* m, float* v, const float* g, const float* norm_coef, int64_t n, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, int32_t step, bl_bf16* p_bf16,
+                            void* stream) {
+  if (!p || !m || !v || !g) return BL_E_ARG;
+  if (n <= 0 || step <= 0) return BL_E_SHAPE;
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, m, v, g, norm_coef,
+                     (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, p_bf16);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_embed_backward_bf16(const int64_t* ids, int32_t B, int32_t L, const bl_bf16* dx, int32_t dim,
+                                      int32_t n_patches, float* dw, void* stream) {
+  if (!ids || !dx || !dw) return BL_E_ARG;
+  if (B <= 0 || L <= 0 || dim <= 0 || (dim % 8) || n_patches < 0) return BL_E_SHAPE;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((long)B * L * (dim / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                     ids, B, L, dx, dim, n_patches, dw);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}

@@ -157,6 +157,46 @@ int bl_argmax_f32(const float* logits, int64_t ld, int32_t rows, int32_t n, int6
 int bl_cross_entropy_f32(const float* logits, int64_t ld, int32_t rows, int32_t n, const int64_t* targets,
                          int64_t ignore_index, float* row_loss, float* mean_and_count, void* stream);
 
+/* ---- training step: backward + optimizer (base_strategy.py:284-366, fsdp.py:190-246) --------------------------------- */
+/* Activation gradients are bf16, parameter gradients / AdamW state / master weights fp32 (train.py:156-157,
+ * fsdp.py:140-146). Reductions are deterministic (per-block partials in caller-provided workspaces + a second pass). */
+/* dlogits = (softmax(logits) - onehot(target)) / n_valid (0 on ignored rows); mean_and_count from bl_cross_entropy_f32. */
+int bl_cross_entropy_backward_f32(const float* logits, int64_t ld, int32_t rows, int32_t n, const int64_t* targets,
+                                  int64_t ignore_index, const float* mean_and_count, bl_bf16* dlogits, int64_t ldd,
+                                  void* stream);
+/* LlamaRMSNorm backward: dx = rstd*(w*dy - xhat*mean(w*dy*xhat)) [+ dres: the residual stream's own gradient];
+ * dw[j] = sum_rows dy*bf16(xhat). partial_ws >= ceil(rows/64)*dim floats. */
+int bl_rmsnorm_backward_bf16(const bl_bf16* x, int64_t ldx, const bl_bf16* w, const bl_bf16* dy, int64_t lddy,
+                             const bl_bf16* dres, int64_t lddres, bl_bf16* dx, int64_t lddx, float* dw, float* partial_ws,
+                             int64_t partial_ws_floats, int32_t rows, int32_t dim, float eps, void* stream);
+/* out[c] = sum_r a[r][c] (bias gradients). partial_ws >= ceil(rows/256)*cols floats. */
+int bl_colsum_bf16(const bl_bf16* a, int64_t lda, int32_t rows, int32_t cols, float* out, float* partial_ws,
+                   int64_t partial_ws_floats, void* stream);
+/* SwiGLU on an interleaved [rows, 2*inter] gate/up buffer (the training forward keeps it for the backward). */
+int bl_swiglu_bf16(const bl_bf16* gu, int64_t ldg, bl_bf16* act, int64_t lda, int64_t rows, int32_t inter, void* stream);
+int bl_swiglu_backward_bf16(const bl_bf16* gu, int64_t ldg, const bl_bf16* dact, int64_t ldd, bl_bf16* dgu, int64_t ldo,
+                            int64_t rows, int32_t inter, void* stream);
+/* exact-erf GELU and its derivative on flat tensors (projector: nn_utils.py:42-48). */
+int bl_gelu_bf16(const bl_bf16* x, bl_bf16* y, int64_t n, void* stream);
+int bl_gelu_backward_bf16(const bl_bf16* x, const bl_bf16* dy, bl_bf16* dx, int64_t n, void* stream);
+/* Transposed rotation on the q and k thirds of dqkv [B*S, 3*H*hd], in place. */
+int bl_rope_backward_bf16(bl_bf16* dqkv, int32_t B, int32_t S, int32_t H, int32_t hd, const bl_bf16* cos_tab,
+                          const bl_bf16* sin_tab, int32_t pos0, void* stream);
+/* out[c][r] = in[r][c], rows padded with zeros to rows_pad (the reduction dim of a wgrad GEMM must be a multiple of 64). */
+int bl_transpose_pad_bf16(const bl_bf16* in, int64_t ldi, int32_t rows, int32_t cols, bl_bf16* out, int64_t ldo,
+                          int32_t rows_pad, void* stream);
+/* Global gradient norm (fsdp.py:268-270): per-tensor partial sums of squares, then norm and clip coefficient
+ * out_norm_coef = {||g||, min(1, max_norm / (||g|| + 1e-6))} (torch.nn.utils.clip_grad_norm_). */
+int bl_sumsq_partial_f32(const float* g, int64_t n, float* partial, int32_t nblocks, void* stream);
+int bl_clip_coef_f32(const float* partial, int32_t n, float max_norm, float* out_norm_coef, void* stream);
+/* torch.optim.AdamW step `step` (1-based) on fp32 master weights; g is scaled by norm_coef[1] when given; p_bf16
+ * (optional) receives the bf16 copy of the updated weights. */
+int bl_adamw_f32(float* p, float* m, float* v, const float* g, const float* norm_coef, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int32_t step, bl_bf16* p_bf16, void* stream);
+/* dW_embed[ids[b,j]] += dx[b, row(j)] over the text positions of the multimodal splice (fp32 atomics; dw pre-zeroed). */
+int bl_embed_backward_bf16(const int64_t* ids, int32_t B, int32_t L, const bl_bf16* dx, int32_t dim, int32_t n_patches,
+                           float* dw, void* stream);
+
 /* ---- vision glue ------------------------------------------------------------------------------------------- */
 /* pixel_values [B, 6, 224, 224] bf16 (processing_prismatic.py:128-145 layout) → 14x14 patch rows for one tower:
  * out[b*256 + py*16 + px, c*196 + i*14 + j] = pixel_values[b, chan0 + c, py*14 + i, px*14 + j]; columns 588..ld-1

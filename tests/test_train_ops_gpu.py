@@ -1,0 +1,158 @@
+"""GPU parity of the backward / optimizer kernels against torch.autograd over the CPU oracle's forward functions
+(oracle/restate.py in bf16-rounding mode: casts are identity in the backward) and against torch.optim.AdamW."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rand_bf16
+from oracle import restate as R
+from test_ops_gpu import close_bf16, dv
+
+pytestmark = pytest.mark.gpu
+P = R.Prec(True)
+
+
+def grad_close(got, ref, what, tol=2e-2):
+    got, ref = got.float().cpu(), ref.float()
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g}"
+
+
+def test_cross_entropy_backward(dev):
+    from bridgelang_amd import ops, train_ops as T
+    rows, V = 24, 32064
+    g = torch.Generator().manual_seed(0)
+    logits = (torch.randn(rows, V, generator=g) * 2).to(torch.bfloat16).float()
+    tgt = torch.randint(0, V, (rows,), generator=g)
+    tgt[::3] = -100
+    lg = logits.clone().requires_grad_(True)
+    loss = torch.nn.functional.cross_entropy(lg, tgt, ignore_index=-100)
+    loss.backward()
+    L, Tg = logits.to(dev), tgt.to(dev)
+    row_loss, mc = torch.empty(rows, device=dev), torch.empty(2, device=dev)
+    ops.cross_entropy(L, Tg, row_loss, mc)
+    assert abs(mc[0].item() - loss.item()) < 1e-4 * abs(loss.item())
+    dl = torch.empty(rows, V, dtype=torch.bfloat16, device=dev)
+    T.cross_entropy_backward(L, Tg, mc, dl)
+    grad_close(dl, lg.grad, "dlogits", 1e-2)
+    assert (dl.cpu()[::3] == 0).all()
+
+
+@pytest.mark.parametrize("rows,dim", [(70, 512), (300, 4096)])
+def test_rmsnorm_backward(dev, rows, dim):
+    from bridgelang_amd import train_ops as T
+    x, w, dy, dres = rand_bf16((rows, dim), 1, 2.0), P.rb(rand_bf16((dim,), 2, 0.02) + 1), rand_bf16((rows, dim), 3), rand_bf16((rows, dim), 4)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = R.rmsnorm(P, xr, wr, 1e-6)
+    (y * dy).sum().backward()
+    dx = torch.empty(rows, dim, dtype=torch.bfloat16, device=dev)
+    dw = torch.empty(dim, device=dev)
+    ws = torch.empty(((rows + 63) // 64) * dim, device=dev)
+    T.rmsnorm_backward(dv(x, dev), dv(w, dev), dv(dy, dev), dx, dw, ws, 1e-6, dres=dv(dres, dev))
+    grad_close(dx, xr.grad + dres, "rmsnorm dx (+residual)")
+    grad_close(dw, wr.grad, "rmsnorm dw")
+    T.rmsnorm_backward(dv(x, dev), dv(w, dev), dv(dy, dev), dx, dw, ws, 1e-6)
+    grad_close(dx, xr.grad, "rmsnorm dx")
+
+
+def test_swiglu_gelu_rope_backward(dev):
+    from bridgelang_amd import train_ops as T
+    M, I = 37, 1536
+    gu, dact = rand_bf16((M, 2 * I), 1, 1.5), rand_bf16((M, I), 2)
+    gur = gu.clone().requires_grad_(True)
+    act = P.rb(P.rb(torch.nn.functional.silu(gur[:, 0::2])) * gur[:, 1::2])
+    (act * dact).sum().backward()
+    A = torch.empty(M, I, dtype=torch.bfloat16, device=dev)
+    T.swiglu(dv(gu, dev), A)
+    close_bf16(A, act.detach(), "swiglu fwd")
+    dgu = torch.empty(M, 2 * I, dtype=torch.bfloat16, device=dev)
+    T.swiglu_backward(dv(gu, dev), dv(dact, dev), dgu)
+    grad_close(dgu, gur.grad, "swiglu bwd")
+    # GELU
+    x, dy = rand_bf16((M, 832), 3, 2.0), rand_bf16((M, 832), 4)
+    xr = x.clone().requires_grad_(True)
+    y = R.gelu(P, xr)
+    (y * dy).sum().backward()
+    Y = torch.empty(M, 832, dtype=torch.bfloat16, device=dev)
+    T.gelu(dv(x, dev), Y)
+    close_bf16(Y, y.detach(), "gelu fwd")
+    dx = torch.empty_like(Y)
+    T.gelu_backward(dv(x, dev), dv(dy, dev), dx)
+    grad_close(dx, xr.grad, "gelu bwd")
+    # RoPE
+    B, S, H, hd = 2, 19, 4, 128
+    D = H * hd
+    qkv, dqkv = rand_bf16((B * S, 3 * D), 5), rand_bf16((B * S, 3 * D), 6)
+    cos, sin = R.rope_tables(hd, 64, 10000.0)
+    qr = qkv.clone().requires_grad_(True)
+    t = qr.view(B, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+    out = torch.stack([R.apply_rope(P, t[0], cos, sin, 0), R.apply_rope(P, t[1], cos, sin, 0), t[2]])
+    (out * dqkv.view(B, S, 3, H, hd).permute(2, 0, 3, 1, 4)).sum().backward()
+    G = dv(dqkv, dev)
+    T.rope_backward(G, dv(cos, dev), dv(sin, dev), B=B, S=S, H=H, head_dim=hd)
+    grad_close(G, qr.grad, "rope bwd")
+
+
+def test_transpose_colsum_wgrad(dev):
+    """wgrad dW = dY^T X as an NT GEMM over transposed, zero-padded, packed operands; bias grad = column sums."""
+    from bridgelang_amd import ops, train_ops as T
+    M, N, K = 300, 192, 256
+    dy, x = rand_bf16((M, N), 1), rand_bf16((M, K), 2)
+    Mp = (M + 63) // 64 * 64
+    dyT = torch.empty(N, Mp, dtype=torch.bfloat16, device=dev)
+    xT = torch.empty(K, Mp, dtype=torch.bfloat16, device=dev)
+    T.transpose_pad(dv(dy, dev), dyT, Mp)
+    T.transpose_pad(dv(x, dev), xT, Mp)
+    assert torch.equal(dyT.cpu().float()[:, :M], dy.t()) and (dyT.cpu()[:, M:] == 0).all()
+    dW = torch.empty(N, K, dtype=torch.float32, device=dev)
+    ops.gemm(dyT, ops.pack_weight(xT), dW, ops.EPI_F32)
+    ref = dy.t() @ x
+    assert torch.allclose(dW.cpu(), ref, rtol=1e-4, atol=1e-4 * ref.abs().max().item())
+    out, ws = torch.empty(N, device=dev), torch.empty(((M + 255) // 256) * N, device=dev)
+    T.colsum(dv(dy, dev), out, ws)
+    assert torch.allclose(out.cpu(), dy.sum(0), rtol=1e-5, atol=1e-4)
+
+
+def test_adamw_and_clip_match_torch(dev):
+    from bridgelang_amd import train_ops as T
+    g = torch.Generator().manual_seed(0)
+    shapes = [(1000,), (64, 129), (7,)]
+    ps = [torch.randn(s, generator=g) for s in shapes]
+    ref_p = [p.clone().requires_grad_(True) for p in ps]
+    opt = torch.optim.AdamW(ref_p, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    dp = [p.clone().to(dev) for p in ps]
+    ms, vs = [torch.zeros_like(p) for p in dp], [torch.zeros_like(p) for p in dp]
+    for step in range(1, 4):
+        grads = [torch.randn(s, generator=g) * (10.0 if step == 2 else 0.1) for s in shapes]
+        for p, gr in zip(ref_p, grads):
+            p.grad = gr.clone()
+        norm_ref = torch.nn.utils.clip_grad_norm_(ref_p, max_norm=1.0)
+        opt.step()
+        dg = [gr.to(dev) for gr in grads]
+        partial = torch.zeros(3 * 8, device=dev)
+        for i, gr in enumerate(dg):
+            T.sumsq_partial(gr.view(-1), partial[i * 8:(i + 1) * 8])
+        nc = torch.empty(2, device=dev)
+        T.clip_coef(partial, 1.0, nc)
+        assert abs(nc[0].item() - norm_ref.item()) <= 1e-5 * norm_ref.item()
+        for p, m, v, gr in zip(dp, ms, vs, dg):
+            bf = torch.empty(p.shape, dtype=torch.bfloat16, device=dev)
+            T.adamw(p.view(-1), m.view(-1), v.view(-1), gr.view(-1), step, 2e-5, weight_decay=0.01, norm_coef=nc, p_bf16=bf)
+            assert torch.equal(bf.float(), p.to(torch.bfloat16).float())
+        for p, r in zip(dp, ref_p):
+            assert torch.allclose(p.cpu(), r.detach(), rtol=1e-6, atol=1e-7), (p.cpu() - r.detach()).abs().max()
+
+
+def test_embed_backward(dev):
+    from bridgelang_amd import train_ops as T
+    B, L, D, V, NP = 2, 6, 64, 50, 4
+    ids = torch.tensor([[1, 5, 7, 5, 9, 2], [1, 5, 3, 3, 3, 2]])
+    dx = rand_bf16((B, L + NP, D), 1)
+    dw = torch.zeros(V, D, device=dev)
+    T.embed_backward(ids.to(dev), dv(dx, dev), dw, NP)
+    ref = torch.zeros(V, D)
+    for b in range(B):
+        for j in range(L):
+            ref[ids[b, j]] += dx[b, 0 if j == 0 else j + NP]
+    assert torch.allclose(dw.cpu(), ref, atol=1e-5)
