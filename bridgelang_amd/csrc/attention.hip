@@ -25,6 +25,8 @@ struct AttnArgs {
   long q_bs, q_hs, q_rs, k_bs, k_hs, k_rs, v_bs, v_hs, v_rs, o_bs, o_hs, o_rs, mask_bs;
   int B, H, Sq, Skv;
   float scale_log2e;
+  float* lse;      // optional [B*H, lse_rs] base-2 log-sum-exp of the scaled scores (training forward); +inf for empty rows
+  int lse_rs;
 };
 
 constexpr int KV_CHUNK = 64;
@@ -168,6 +170,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
   const float inv = l > 0.f ? 1.0f / l : 0.f;
+  if (p.lse && lg == 0 && qrow < p.Sq)
+    p.lse[((long)b * p.H + h) * p.lse_rs + qrow] = l > 0.f ? m_run + __builtin_amdgcn_logf(l) : INFINITY;
   if (qrow < p.Sq) {
     uint16_t* op = p.o + (long)b * p.o_bs + (long)h * p.o_hs + (long)qrow * p.o_rs;
 #pragma unroll
@@ -325,6 +329,8 @@ __global__ __launch_bounds__(512) void attn_seq_kernel(AttnArgs p, int s_pad) {
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
+    if (p.lse && lg == 0 && qrow < p.Sq)
+      p.lse[((long)b * p.H + h) * p.lse_rs + qrow] = l > 0.f ? m_use + __builtin_amdgcn_logf(l) : INFINITY;
     if (qrow < p.Sq) {
       uint16_t* op = p.o + (long)b * p.o_bs + (long)h * p.o_hs + (long)qrow * p.o_rs;
 #pragma unroll
@@ -487,6 +493,7 @@ int fill_args(const bl_attn_desc* d, AttnArgs& a) {
   a.mask_bs = d->mask_bs;
   a.B = d->B; a.H = d->H; a.Sq = d->Sq; a.Skv = d->Skv;
   a.scale_log2e = d->scale * 1.44269504088896340736f;
+  a.lse = nullptr; a.lse_rs = 0;
   return BL_OK;
 }
 
@@ -509,11 +516,12 @@ int launch_seq(const AttnArgs& a, const bl_attn_desc* d, hipStream_t s) {
   return BL_OK;
 }
 
-extern "C" int bl_attention_bf16(const bl_attn_desc* d, void* stream) {
+static int attention_launch(const bl_attn_desc* d, float* lse, void* stream) {
   AttnArgs a;
   const int rc = fill_args(d, a);
   if (rc != BL_OK) return rc;
   if (d->causal && d->Skv < d->Sq) return BL_E_SHAPE;
+  a.lse = lse; a.lse_rs = (d->Sq + 31) / 32 * 32;
   hipStream_t s = (hipStream_t)stream;
   static const bool chunked_only = getenv("BL_ATTN_CHUNKED") != nullptr;   // A/B aid
   // short sequences (the whole OpenVLA path): K and V of a head fit in LDS → whole-sequence kernel
@@ -539,6 +547,13 @@ extern "C" int bl_attention_bf16(const bl_attn_desc* d, void* stream) {
 #undef BL_ATTN_CASE
   BL_CHECK_LAUNCH();
   return BL_OK;
+}
+
+extern "C" int bl_attention_bf16(const bl_attn_desc* d, void* stream) { return attention_launch(d, nullptr, stream); }
+
+extern "C" int bl_attention_lse_bf16(const bl_attn_desc* d, float* lse, void* stream) {
+  if (!lse) return BL_E_ARG;
+  return attention_launch(d, lse, stream);
 }
 
 extern "C" int bl_attention_decode_bf16(const bl_attn_desc* d, void* stream) {

@@ -98,3 +98,29 @@ def embed_backward(ids, dx, dw, n_patches: int) -> None:
     B, L = ids.shape
     _ck(_lib.load().bl_embed_backward_bf16(ids.data_ptr(), B, L, _bf16(dx, "dx").data_ptr(), dx.shape[-1], n_patches,
                                            dw.data_ptr(), _stream()), "bl_embed_backward_bf16")
+
+
+def _adesc(q, k, v, o, B, H, Sq, Skv, head_dim, qs, ks, vs, os_, causal, scale, key_mask):
+    from .ops import _attn_desc
+    return _attn_desc(q, k, v, o, B, H, Sq, Skv, head_dim, qs, ks, vs, os_, causal,
+                      head_dim ** -0.5 if scale is None else scale, key_mask)
+
+
+def attention_lse(q, k, v, o, lse, *, B, H, Sq, Skv, head_dim, q_strides, k_strides, v_strides, o_strides, causal,
+                  scale=None, key_mask=None) -> None:
+    """Training forward: attention + per-row base-2 log-sum-exp (lse: fp32 [B*H*pad32(Sq)])."""
+    assert lse.dtype == torch.float32 and lse.numel() >= B * H * ((Sq + 31) // 32 * 32)
+    d = _adesc(q, k, v, o, B, H, Sq, Skv, head_dim, q_strides, k_strides, v_strides, o_strides, causal, scale, key_mask)
+    import ctypes as C
+    _ck(_lib.load().bl_attention_lse_bf16(C.byref(d), lse.data_ptr(), _stream()), "bl_attention_lse_bf16")
+
+
+def attention_backward(q, k, v, o, dout, lse, delta, dq, dk, dv, *, B, H, Sq, Skv, head_dim, q_strides, k_strides,
+                       v_strides, o_strides, causal, scale=None, key_mask=None) -> None:
+    for t in (lse, delta):
+        assert t.dtype == torch.float32 and t.numel() >= B * H * ((Sq + 31) // 32 * 32)
+    d = _adesc(q, k, v, o, B, H, Sq, Skv, head_dim, q_strides, k_strides, v_strides, o_strides, causal, scale, key_mask)
+    import ctypes as C
+    _ck(_lib.load().bl_attention_backward_bf16(C.byref(d), _bf16(dout, "dout").data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                               _bf16(dq, "dq").data_ptr(), _bf16(dk, "dk").data_ptr(),
+                                               _bf16(dv, "dv").data_ptr(), _stream()), "bl_attention_backward_bf16")

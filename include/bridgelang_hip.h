@@ -126,6 +126,16 @@ typedef struct bl_attn_desc {
   float scale;         /* head_dim^-0.5 */
 } bl_attn_desc;
 int bl_attention_bf16(const bl_attn_desc* d, void* stream);
+/* Training forward: as bl_attention_bf16, and also writes the base-2 log-sum-exp of the scaled scores of every query
+ * row to lse[(b*H + h) * pad32(Sq) + i] (fp32; +inf for a row with no visible key) for bl_attention_backward_bf16. */
+int bl_attention_lse_bf16(const bl_attn_desc* d, float* lse, void* stream);
+/* Backward of bl_attention_bf16 (what autograd runs under HF LlamaAttention / timm Attention in the reference's
+ * `loss.backward()`, prismatic/training/strategies/base_strategy.py:300). d describes the forward call (o = its
+ * output); dout uses o's strides; dq / dk / dv use q's / k's / v's strides (so they can alias the three thirds of a
+ * fused dqkv row). lse from bl_attention_lse_bf16; delta is scratch of the same size, [B*H*pad32(Sq)] fp32.
+ * Sq, Skv <= 320 (the whole-sequence kernels; all strides multiples of 8). */
+int bl_attention_backward_bf16(const bl_attn_desc* d, const bl_bf16* dout, const float* lse, float* delta, bl_bf16* dq,
+                               bl_bf16* dk, bl_bf16* dv, void* stream);
 /* Single-query decode attention over a KV cache; kv_len = number of valid keys (same for the whole batch). */
 int bl_attention_decode_bf16(const bl_attn_desc* d, void* stream);
 

@@ -156,3 +156,57 @@ def test_embed_backward(dev):
         for j in range(L):
             ref[ids[b, j]] += dx[b, 0 if j == 0 else j + NP]
     assert torch.allclose(dw.cpu(), ref, atol=1e-5)
+
+
+@pytest.mark.parametrize("hd,H,S,causal,masked", [(128, 4, 290, True, False), (128, 2, 100, True, True), (128, 2, 33, True, False),
+                                                  (64, 4, 257, False, False), (72, 2, 256, False, False)])
+def test_attention_backward(dev, hd, H, S, causal, masked):
+    """dQ/dK/dV of the whole-sequence attention vs autograd over the oracle's attention (fused qkv-row strides, so the
+    grads land in the three thirds of one dqkv buffer as the training step uses them)."""
+    from bridgelang_amd import train_ops as T
+    B, D = 3, H * hd
+    qkv, dout = rand_bf16((B * S, 3 * D), hd + S), rand_bf16((B * S, D), 7)
+    mask = None
+    lens = [S] * B
+    if masked:
+        lens = [S, 63, 17]
+        mask = torch.zeros(B, S, dtype=torch.uint8)
+        for i, n in enumerate(lens):
+            mask[i, :n] = 1
+    valid = torch.zeros(B, S, 1, 1)
+    for i, n in enumerate(lens):
+        valid[i, :n] = 1
+    qr = qkv.clone().requires_grad_(True)
+    t = qr.view(B, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref_o = R.attention(P, t[0], t[1], t[2], hd ** -0.5, causal, key_mask=mask).permute(0, 2, 1, 3)   # [B,S,H,hd]
+    g_o = dout.view(B, S, H, hd) * valid           # padded query rows carry no gradient (their loss labels are -100)
+    (ref_o * g_o).sum().backward()
+    Q, G = dv(qkv, dev), dv(g_o.reshape(B * S, D), dev)
+    o = torch.zeros(B * S, D, dtype=torch.bfloat16, device=dev)
+    pad = (S + 31) // 32 * 32
+    lse = torch.full((B * H * pad,), float("nan"), device=dev)
+    delta = torch.full((B * H * pad,), float("nan"), device=dev)
+    st, so = (S * 3 * D, hd, 3 * D), (S * D, hd, D)
+    kw = dict(B=B, H=H, Sq=S, Skv=S, head_dim=hd, q_strides=st, k_strides=st, v_strides=st, o_strides=so, causal=causal,
+              key_mask=mask.to(dev) if masked else None)
+    T.attention_lse(Q, Q[:, D:], Q[:, 2 * D:], o, lse, **kw)
+    got_o = o.cpu().float().view(B, S, H, hd)
+    for i, n in enumerate(lens):
+        close_bf16(got_o[i, :n], ref_o.detach()[i, :n], "attention fwd (lse variant)", rtol=2 ** -5, atol_scale=2 ** -7, min_exact=0.55)
+    # lse against the oracle's scores
+    with torch.no_grad():
+        s = (t[0] @ t[1].transpose(-1, -2)) * hd ** -0.5
+        if causal:
+            s = s.masked_fill(torch.ones(S, S, dtype=torch.bool).triu(1), float("-inf"))
+        if masked:
+            s = s.masked_fill(~mask.bool().view(B, 1, 1, S), float("-inf"))
+        lse_ref = torch.logsumexp(s, -1) / np.log(2.0)
+    lse_got = lse.cpu().view(B, H, pad)[:, :, :S]
+    for i, n in enumerate(lens):
+        assert torch.allclose(lse_got[i, :, :n], lse_ref[i, :, :n], rtol=1e-4, atol=1e-3)
+    dqkv = torch.zeros(B * S, 3 * D, dtype=torch.bfloat16, device=dev)
+    T.attention_backward(Q, Q[:, D:], Q[:, 2 * D:], o, G, lse, delta, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], **kw)
+    got, ref = dqkv.cpu().float().view(B, S, 3, H, hd), qr.grad.view(B, S, 3, H, hd)
+    for i, n in enumerate(lens):
+        for j, nm in enumerate("qkv"):
+            grad_close(got[i, :n, j], ref[i, :n, j], f"d{nm} b={i}", tol=2.5e-2)
