@@ -88,6 +88,8 @@ SIGNATURES = {
     "bl_sumsq_partial_f32": (C.c_int, [_vp, _i64, _vp, _i32, _vp]),
     "bl_clip_coef_f32": (C.c_int, [_vp, _i32, _f32, _vp, _vp]),
     "bl_adamw_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
+    "bl_rope_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "bl_map_rows_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "bl_embed_backward_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "bl_im2col_patch14_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _vp]),
     "bl_write_prefix_tokens_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp]),

@@ -67,11 +67,12 @@ __global__ void rope_kvcache_kernel(uint16_t* qkv, int B, int S, int H, int hd, 
         o1[w] = pack2bf(r1[0], r1[1]);
         o2[w] = pack2bf(r2[0], r2[1]);
       }
-      uint16_t* dst = part == 0 ? src : (k_cache + cache_off);
+      uint16_t* dst = (part == 0 || !k_cache) ? src : (k_cache + cache_off);   // no cache: rotate k in place
       *(u32x4_t*)(dst + ch * 8) = o1;
       *(u32x4_t*)(dst + half + ch * 8) = o2;
     }
     // v: plain copy into the cache (two chunks per thread cover the head together with the other threads)
+    if (!v_cache) continue;
     const uint16_t* vsrc = row + 2 * D + (long)h * hd;
     uint16_t* vdst = v_cache + cache_off;
     *(u32x4_t*)(vdst + ch * 8) = *(const u32x4_t*)(vsrc + ch * 8);
@@ -269,6 +270,18 @@ extern "C" int bl_rope_kvcache_bf16(bl_bf16* qkv, int32_t B, int32_t S, int32_t 
   const long total = (long)B * S * H * (hd / 16);
   hipLaunchKernelGGL(rope_kvcache_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, qkv, B, S, H,
                      hd, cos_tab, sin_tab, pos0, k_cache, v_cache, cache_len);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_rope_bf16(bl_bf16* qkv, int32_t B, int32_t S, int32_t H, int32_t hd, const bl_bf16* cos_tab,
+                            const bl_bf16* sin_tab, int32_t pos0, void* stream) {
+  if (!qkv || !cos_tab || !sin_tab) return BL_E_ARG;
+  if (B <= 0 || S <= 0 || H <= 0 || hd <= 0 || (hd % 16) || pos0 < 0) return BL_E_SHAPE;
+  if (!bl_aligned16(qkv) || !bl_aligned16(cos_tab) || !bl_aligned16(sin_tab)) return BL_E_ALIGN;
+  const long total = (long)B * S * H * (hd / 16);
+  hipLaunchKernelGGL(rope_kvcache_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, qkv, B, S, H,
+                     hd, cos_tab, sin_tab, pos0, (uint16_t*)nullptr, (uint16_t*)nullptr, 0);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

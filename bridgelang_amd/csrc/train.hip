@@ -251,6 +251,21 @@ __global__ void rope_bwd_kernel(uint16_t* dqkv, int B, int S, int H, int hd, con
   }
 }
 
+// ---- row gather / scatter: out row r ↔ src row (r / group) * stride + offset + r % group (the projector's 256 patch rows
+//      inside the [B, S, D] embedding buffer) ----
+__global__ void map_rows_kernel(const uint16_t* src, long lds_, uint16_t* dst, long ldd, long rows, int cols, int group,
+                                int stride, int offset, int scatter) {
+  const int cpr = cols >> 3;
+  const long total = rows * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cpr;
+    const int ch = (int)(i - r * cpr);
+    const long m = (r / group) * stride + offset + r % group;
+    const long rs = scatter ? r : m, rd = scatter ? m : r;
+    *(u32x4_t*)(dst + rd * ldd + ch * 8) = *(const u32x4_t*)(src + rs * lds_ + ch * 8);
+  }
+}
+
 // ---- transpose bf16 [rows, cols] → [cols, rows_pad] (rows_pad ≥ rows, pad zero-filled): feeds the wgrad GEMMs ----
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const uint16_t* in, long ldi, int rows, int cols,
                                                             uint16_t* out, long ldo, int rows_pad) {
@@ -418,6 +433,17 @@ extern "C" int bl_rope_backward_bf16(bl_bf16* dqkv, int32_t B, int32_t S, int32_
   const long total = (long)B * S * H * (hd / 16) * 2;
   hipLaunchKernelGGL(rope_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, dqkv, B, S, H, hd,
                      cos_tab, sin_tab, pos0);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_map_rows_bf16(const bl_bf16* src, int64_t ld_src, bl_bf16* dst, int64_t ld_dst, int64_t rows, int32_t cols,
+                                int32_t group, int32_t stride, int32_t offset, int32_t scatter, void* stream) {
+  if (!src || !dst) return BL_E_ARG;
+  if (rows <= 0 || cols <= 0 || (cols % 8) || group <= 0 || stride < 0 || (ld_src % 8) || (ld_dst % 8)) return BL_E_SHAPE;
+  if (!bl_aligned16(src) || !bl_aligned16(dst)) return BL_E_ALIGN;
+  hipLaunchKernelGGL(map_rows_kernel, dim3(grid_for(rows * (cols / 8), 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     (long)ld_src, dst, (long)ld_dst, (long)rows, cols, group, stride, offset, scatter);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

@@ -1,126 +1,153 @@
-"""Torch-tensor front end for the training-step entry points of the C ABI (backward + optimizer kernels, train.hip).
-Immediate-mode wrappers: each call enqueues its kernel(s) on the current stream."""
+"""Torch-tensor front end for the training-step entry points of the C ABI (train.hip, attention_bwd.hip).
+Same convention as ops.py: every builder returns a prepared `Op` and (run=True) enqueues it on the current stream."""
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional
 
 import torch
 
 from . import _lib
-from .ops import _bf16, _rows, _stream
+from .ops import Op, _attn_desc, _bf16, _rows
 
 
-def _ck(rc: int, name: str) -> None:
-    if rc != 0:
-        _lib.check(rc, name)
+def _op(name: str, args: tuple, keep: tuple, run: bool, nbytes: float = 0.0, flops: float = 0.0) -> Op:
+    op = Op(name, getattr(_lib.load(), name), args, keep, flops=flops, nbytes=nbytes)
+    if run:
+        op.run()
+    return op
 
 
-def cross_entropy_backward(logits: torch.Tensor, targets: torch.Tensor, mean_and_count: torch.Tensor,
-                           dlogits: torch.Tensor, ignore_index: int = -100) -> None:
+def _f32(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise TypeError(f"{what}: expected a CUDA/HIP float32 tensor, got {t.dtype} on {t.device}")
+    return t
+
+
+def cross_entropy_backward(logits, targets, mean_and_count, dlogits, ignore_index: int = -100, run: bool = True) -> Op:
     rows, n = logits.shape
-    _ck(_lib.load().bl_cross_entropy_backward_f32(logits.data_ptr(), _rows(logits, "logits"), rows, n, targets.data_ptr(),
-                                                  ignore_index, mean_and_count.data_ptr(), _bf16(dlogits, "dlogits").data_ptr(),
-                                                  _rows(dlogits, "dlogits"), _stream()), "bl_cross_entropy_backward_f32")
+    return _op("bl_cross_entropy_backward_f32",
+               (_f32(logits, "logits").data_ptr(), _rows(logits, "logits"), rows, n, targets.data_ptr(), ignore_index,
+                mean_and_count.data_ptr(), _bf16(dlogits, "dlogits").data_ptr(), _rows(dlogits, "dlogits")),
+               (logits, targets, mean_and_count, dlogits), run, nbytes=6.0 * rows * n)
 
 
-def rmsnorm_backward(x, w, dy, dx, dw, ws, eps: float, dres: Optional[torch.Tensor] = None) -> None:
+def rmsnorm_backward(x, w, dy, dx, dw, ws, eps: float, dres: Optional[torch.Tensor] = None, run: bool = True) -> Op:
     rows, dim = x.shape
-    _ck(_lib.load().bl_rmsnorm_backward_bf16(
-        _bf16(x, "x").data_ptr(), _rows(x, "x"), _bf16(w, "w").data_ptr(), _bf16(dy, "dy").data_ptr(), _rows(dy, "dy"),
-        dres.data_ptr() if dres is not None else None, _rows(dres, "dres") if dres is not None else 0,
-        _bf16(dx, "dx").data_ptr(), _rows(dx, "dx"), dw.data_ptr(), ws.data_ptr(), ws.numel(), rows, dim, float(eps),
-        _stream()), "bl_rmsnorm_backward_bf16")
+    return _op("bl_rmsnorm_backward_bf16",
+               (_bf16(x, "x").data_ptr(), _rows(x, "x"), _bf16(w, "w").data_ptr(), _bf16(dy, "dy").data_ptr(), _rows(dy, "dy"),
+                dres.data_ptr() if dres is not None else None, _rows(dres, "dres") if dres is not None else 0,
+                _bf16(dx, "dx").data_ptr(), _rows(dx, "dx"), _f32(dw, "dw").data_ptr(), _f32(ws, "ws").data_ptr(), ws.numel(),
+                rows, dim, float(eps)), (x, w, dy, dx, dw, ws, dres), run, nbytes=2.0 * rows * dim * (4 if dres is not None else 3))
 
 
-def colsum(a, out, ws) -> None:
+def colsum(a, out, ws, run: bool = True) -> Op:
     rows, cols = a.shape
-    _ck(_lib.load().bl_colsum_bf16(_bf16(a, "a").data_ptr(), _rows(a, "a"), rows, cols, out.data_ptr(), ws.data_ptr(),
-                                   ws.numel(), _stream()), "bl_colsum_bf16")
+    return _op("bl_colsum_bf16", (_bf16(a, "a").data_ptr(), _rows(a, "a"), rows, cols, _f32(out, "out").data_ptr(),
+                                  _f32(ws, "ws").data_ptr(), ws.numel()), (a, out, ws), run, nbytes=2.0 * rows * cols)
 
 
-def swiglu(gu, act) -> None:
+def swiglu(gu, act, run: bool = True) -> Op:
     rows, two_i = gu.shape
-    _ck(_lib.load().bl_swiglu_bf16(_bf16(gu, "gu").data_ptr(), _rows(gu, "gu"), _bf16(act, "act").data_ptr(), _rows(act, "act"),
-                                   rows, two_i // 2, _stream()), "bl_swiglu_bf16")
+    return _op("bl_swiglu_bf16", (_bf16(gu, "gu").data_ptr(), _rows(gu, "gu"), _bf16(act, "act").data_ptr(), _rows(act, "act"),
+                                  rows, two_i // 2), (gu, act), run, nbytes=3.0 * rows * two_i)
 
 
-def swiglu_backward(gu, dact, dgu) -> None:
+def swiglu_backward(gu, dact, dgu, run: bool = True) -> Op:
     rows, two_i = gu.shape
-    _ck(_lib.load().bl_swiglu_backward_bf16(_bf16(gu, "gu").data_ptr(), _rows(gu, "gu"), _bf16(dact, "dact").data_ptr(),
-                                            _rows(dact, "dact"), _bf16(dgu, "dgu").data_ptr(), _rows(dgu, "dgu"), rows,
-                                            two_i // 2, _stream()), "bl_swiglu_backward_bf16")
+    return _op("bl_swiglu_backward_bf16",
+               (_bf16(gu, "gu").data_ptr(), _rows(gu, "gu"), _bf16(dact, "dact").data_ptr(), _rows(dact, "dact"),
+                _bf16(dgu, "dgu").data_ptr(), _rows(dgu, "dgu"), rows, two_i // 2), (gu, dact, dgu), run, nbytes=5.0 * rows * two_i)
 
 
-def gelu(x, y) -> None:
+def gelu(x, y, run: bool = True) -> Op:
     assert x.is_contiguous() and y.is_contiguous()
-    _ck(_lib.load().bl_gelu_bf16(_bf16(x, "x").data_ptr(), _bf16(y, "y").data_ptr(), x.numel(), _stream()), "bl_gelu_bf16")
+    return _op("bl_gelu_bf16", (_bf16(x, "x").data_ptr(), _bf16(y, "y").data_ptr(), x.numel()), (x, y), run, nbytes=4.0 * x.numel())
 
 
-def gelu_backward(x, dy, dx) -> None:
+def gelu_backward(x, dy, dx, run: bool = True) -> Op:
     assert x.is_contiguous() and dy.is_contiguous() and dx.is_contiguous()
-    _ck(_lib.load().bl_gelu_backward_bf16(_bf16(x, "x").data_ptr(), _bf16(dy, "dy").data_ptr(), _bf16(dx, "dx").data_ptr(),
-                                          x.numel(), _stream()), "bl_gelu_backward_bf16")
+    return _op("bl_gelu_backward_bf16", (_bf16(x, "x").data_ptr(), _bf16(dy, "dy").data_ptr(), _bf16(dx, "dx").data_ptr(),
+                                         x.numel()), (x, dy, dx), run, nbytes=6.0 * x.numel())
 
 
-def rope_backward(dqkv, cos, sin, *, B: int, S: int, H: int, head_dim: int, pos0: int = 0) -> None:
+def rope(qkv, cos, sin, *, B: int, S: int, H: int, head_dim: int, pos0: int = 0, run: bool = True) -> Op:
+    """Rotate the q and k thirds of fused qkv rows in place (training forward: no KV cache)."""
+    assert qkv.is_contiguous()
+    return _op("bl_rope_bf16", (_bf16(qkv, "qkv").data_ptr(), B, S, H, head_dim, cos.data_ptr(), sin.data_ptr(), pos0),
+               (qkv, cos, sin), run, nbytes=8.0 * B * S * H * head_dim)
+
+
+def rope_backward(dqkv, cos, sin, *, B: int, S: int, H: int, head_dim: int, pos0: int = 0, run: bool = True) -> Op:
     assert dqkv.is_contiguous()
-    _ck(_lib.load().bl_rope_backward_bf16(_bf16(dqkv, "dqkv").data_ptr(), B, S, H, head_dim, cos.data_ptr(), sin.data_ptr(),
-                                          pos0, _stream()), "bl_rope_backward_bf16")
+    return _op("bl_rope_backward_bf16", (_bf16(dqkv, "dqkv").data_ptr(), B, S, H, head_dim, cos.data_ptr(), sin.data_ptr(), pos0),
+               (dqkv, cos, sin), run, nbytes=8.0 * B * S * H * head_dim)
 
 
-def transpose_pad(a, out, rows_pad: int) -> None:
+def transpose_pad(a, out, rows_pad: int, run: bool = True) -> Op:
     rows, cols = a.shape
-    _ck(_lib.load().bl_transpose_pad_bf16(_bf16(a, "a").data_ptr(), _rows(a, "a"), rows, cols, _bf16(out, "out").data_ptr(),
-                                          _rows(out, "out"), rows_pad, _stream()), "bl_transpose_pad_bf16")
+    return _op("bl_transpose_pad_bf16", (_bf16(a, "a").data_ptr(), _rows(a, "a"), rows, cols, _bf16(out, "out").data_ptr(),
+                                         _rows(out, "out"), rows_pad), (a, out), run, nbytes=2.0 * cols * (rows + rows_pad))
 
 
-def sumsq_partial(g: torch.Tensor, partial: torch.Tensor) -> None:
-    _ck(_lib.load().bl_sumsq_partial_f32(g.data_ptr(), g.numel(), partial.data_ptr(), partial.numel(), _stream()),
-        "bl_sumsq_partial_f32")
+def map_rows(src, dst, *, rows: int, group: int, stride: int, offset: int, scatter: bool, run: bool = True) -> Op:
+    cols = src.shape[1]
+    return _op("bl_map_rows_bf16", (_bf16(src, "src").data_ptr(), _rows(src, "src"), _bf16(dst, "dst").data_ptr(), _rows(dst, "dst"),
+                                    rows, cols, group, stride, offset, int(scatter)), (src, dst), run, nbytes=4.0 * rows * cols)
 
 
-def clip_coef(partials: torch.Tensor, max_norm: float, out: torch.Tensor) -> None:
-    _ck(_lib.load().bl_clip_coef_f32(partials.data_ptr(), partials.numel(), float(max_norm), out.data_ptr(), _stream()),
-        "bl_clip_coef_f32")
+def sumsq_partial(g: torch.Tensor, partial: torch.Tensor, run: bool = True) -> Op:
+    return _op("bl_sumsq_partial_f32", (_f32(g, "g").data_ptr(), g.numel(), _f32(partial, "partial").data_ptr(), partial.numel()),
+               (g, partial), run, nbytes=4.0 * g.numel())
+
+
+def clip_coef(partials: torch.Tensor, max_norm: float, out: torch.Tensor, run: bool = True) -> Op:
+    return _op("bl_clip_coef_f32", (partials.data_ptr(), partials.numel(), float(max_norm), out.data_ptr()), (partials, out), run)
 
 
 def adamw(p, m, v, g, step: int, lr: float, *, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-          norm_coef: Optional[torch.Tensor] = None, p_bf16: Optional[torch.Tensor] = None) -> None:
+          norm_coef: Optional[torch.Tensor] = None, p_bf16: Optional[torch.Tensor] = None, run: bool = True) -> Op:
     for t in (p, m, v, g):
         assert t.dtype == torch.float32 and t.is_contiguous()
-    _ck(_lib.load().bl_adamw_f32(p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(),
-                                 norm_coef.data_ptr() if norm_coef is not None else None, p.numel(), float(lr),
-                                 float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step),
-                                 p_bf16.data_ptr() if p_bf16 is not None else None, _stream()), "bl_adamw_f32")
+    return _op("bl_adamw_f32", (p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(),
+                                norm_coef.data_ptr() if norm_coef is not None else None, p.numel(), float(lr), float(betas[0]),
+                                float(betas[1]), float(eps), float(weight_decay), int(step),
+                                p_bf16.data_ptr() if p_bf16 is not None else None), (p, m, v, g, norm_coef, p_bf16), run,
+               nbytes=(28.0 + (2.0 if p_bf16 is not None else 0.0)) * p.numel())
 
 
-def embed_backward(ids, dx, dw, n_patches: int) -> None:
+def embed_backward(ids, dx, dw, n_patches: int, run: bool = True) -> Op:
     B, L = ids.shape
-    _ck(_lib.load().bl_embed_backward_bf16(ids.data_ptr(), B, L, _bf16(dx, "dx").data_ptr(), dx.shape[-1], n_patches,
-                                           dw.data_ptr(), _stream()), "bl_embed_backward_bf16")
-
-
-def _adesc(q, k, v, o, B, H, Sq, Skv, head_dim, qs, ks, vs, os_, causal, scale, key_mask):
-    from .ops import _attn_desc
-    return _attn_desc(q, k, v, o, B, H, Sq, Skv, head_dim, qs, ks, vs, os_, causal,
-                      head_dim ** -0.5 if scale is None else scale, key_mask)
+    return _op("bl_embed_backward_bf16", (ids.data_ptr(), B, L, _bf16(dx, "dx").data_ptr(), dx.shape[-1], n_patches,
+                                          _f32(dw, "dw").data_ptr()), (ids, dx, dw), run)
 
 
 def attention_lse(q, k, v, o, lse, *, B, H, Sq, Skv, head_dim, q_strides, k_strides, v_strides, o_strides, causal,
-                  scale=None, key_mask=None) -> None:
+                  scale=None, key_mask=None, run: bool = True) -> Op:
     """Training forward: attention + per-row base-2 log-sum-exp (lse: fp32 [B*H*pad32(Sq)])."""
-    assert lse.dtype == torch.float32 and lse.numel() >= B * H * ((Sq + 31) // 32 * 32)
-    d = _adesc(q, k, v, o, B, H, Sq, Skv, head_dim, q_strides, k_strides, v_strides, o_strides, causal, scale, key_mask)
-    import ctypes as C
-    _ck(_lib.load().bl_attention_lse_bf16(C.byref(d), lse.data_ptr(), _stream()), "bl_attention_lse_bf16")
+    assert _f32(lse, "lse").numel() >= B * H * ((Sq + 31) // 32 * 32)
+    d = _attn_desc(q, k, v, o, B, H, Sq, Skv, head_dim, q_strides, k_strides, v_strides, o_strides, causal,
+                   head_dim ** -0.5 if scale is None else scale, key_mask)
+    return _op("bl_attention_lse_bf16", (C.byref(d), lse.data_ptr()), (d, q, k, v, o, lse, key_mask), run,
+               flops=4.0 * B * H * Sq * Skv * head_dim * (0.5 if causal else 1.0))
 
 
 def attention_backward(q, k, v, o, dout, lse, delta, dq, dk, dv, *, B, H, Sq, Skv, head_dim, q_strides, k_strides,
-                       v_strides, o_strides, causal, scale=None, key_mask=None) -> None:
+                       v_strides, o_strides, causal, scale=None, key_mask=None, run: bool = True) -> Op:
     for t in (lse, delta):
-        assert t.dtype == torch.float32 and t.numel() >= B * H * ((Sq + 31) // 32 * 32)
-    d = _adesc(q, k, v, o, B, H, Sq, Skv, head_dim, q_strides, k_strides, v_strides, o_strides, causal, scale, key_mask)
-    import ctypes as C
-    _ck(_lib.load().bl_attention_backward_bf16(C.byref(d), _bf16(dout, "dout").data_ptr(), lse.data_ptr(), delta.data_ptr(),
-                                               _bf16(dq, "dq").data_ptr(), _bf16(dk, "dk").data_ptr(),
-                                               _bf16(dv, "dv").data_ptr(), _stream()), "bl_attention_backward_bf16")
+        assert _f32(t, "lse/delta").numel() >= B * H * ((Sq + 31) // 32 * 32)
+    d = _attn_desc(q, k, v, o, B, H, Sq, Skv, head_dim, q_strides, k_strides, v_strides, o_strides, causal,
+                   head_dim ** -0.5 if scale is None else scale, key_mask)
+    return _op("bl_attention_backward_bf16",
+               (C.byref(d), _bf16(dout, "dout").data_ptr(), lse.data_ptr(), delta.data_ptr(), _bf16(dq, "dq").data_ptr(),
+                _bf16(dk, "dk").data_ptr(), _bf16(dv, "dv").data_ptr()), (d, q, k, v, o, dout, lse, delta, dq, dk, dv, key_mask), run,
+               flops=14.0 * B * H * Sq * Skv * head_dim * (0.5 if causal else 1.0))
+
+
+def pack(w: torch.Tensor, out: torch.Tensor, run: bool = True) -> Op:
+    """Row-major [N, K] → fragment-major packed (bl_pack_weight_bf16) as a replayable Op (weights after an optimizer
+    step; the transposed activations of a wgrad GEMM)."""
+    N, K = w.shape
+    assert out.numel() == N * K and N % 16 == 0 and K % 32 == 0
+    return _op("bl_pack_weight_bf16", (_bf16(w, "w").data_ptr(), _rows(w, "w"), N, K, _bf16(out, "out").data_ptr()), (w, out), run,
+               nbytes=4.0 * N * K)

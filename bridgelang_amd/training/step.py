@@ -1,0 +1,458 @@
+"""One optimisation step of OpenVLA training on one MI355X: forward with saved activations, hand-written backward,
+global-norm clip and AdamW — the device side of the reference's `TrainingStrategy.run_vla_training` loop body
+(prismatic/training/strategies/base_strategy.py:296-346) with the module freezing of `PrismaticVLM.freeze_backbones`
+(prismatic/models/vlms/prismatic.py:129-241) and the optimizer grouping of `FSDPStrategy.run_setup`
+(prismatic/training/strategies/fsdp.py:195-236).
+
+MI355X-first choices (DESIGN.md "Training step"):
+  * no autograd, no tracing: the step is three static lists of prepared C calls (forward, backward, repack) over
+    preallocated buffers, so each list replays under a HIP graph;
+  * no activation checkpointing (the reference enables it for 80 GB parts, fsdp.py:176-186): every layer's activations
+    stay resident — ≈ 4.2 MB / token at 7B, 20 GB for 16 × 290 tokens out of 288 GB;
+  * weights live twice in bf16, fragment-major for the forward GEMM ([N,K] packed) and transposed for the dgrad GEMM
+    ([K,N] packed); wgrad is the same NT GEMM kernel over transposed, token-padded activations, accumulating in fp32
+    straight into the flat fp32 gradient buffer;
+  * fp32 master weights and AdamW moments are flat buffers, so the optimizer is a handful of launches; the clip
+    coefficient is consumed on the device (no host sync inside the step).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .. import ops, train_ops as T
+from ..engine import rope_tables
+from ..ops import EPI_BIAS, EPI_F32, EPI_F32_BF16R, EPI_NONE, EPI_RES, Op
+from ..weights import PackedGroup, Placement, VLAWeights, _block_view, _unpack
+
+IGNORE_INDEX = -100
+
+# stage → (vision trainable, projector trainable, llm: "all" | "last" | "none")   — prismatic.py:129-241
+STAGES: Dict[str, Tuple[bool, bool, str]] = {
+    "align": (False, True, "none"),
+    "finetune": (False, True, "all"), "vla-train": (False, True, "all"),
+    "full-finetune": (True, True, "all"), "vla-full-train": (True, True, "all"),
+    "last-layer-finetune": (False, False, "last"), "vla-last-layer-train": (False, False, "last"),
+    "vla-sandwich-train": (True, True, "last"),
+}
+
+
+def trainable_names(w: VLAWeights, stage: str) -> List[str]:
+    """HF tensor names with requires_grad=True after `freeze_backbones(stage)`; "last" = embed_tokens, the final decoder
+    layer and lm_head (llama2.py:101-102; the final norm is not in that tuple and stays frozen)."""
+    if stage not in STAGES:
+        raise ValueError(f"Stage `{stage}` is not supported")
+    vision, proj, llm = STAGES[stage]
+    last = f"language_model.model.layers.{w.dims.llm_layers - 1}."
+    out = []
+    for name in w.placements:
+        if name.startswith("vision_backbone."):
+            ok = vision
+        elif name.startswith("projector."):
+            ok = proj
+        elif llm == "all":
+            ok = True
+        elif llm == "last":
+            ok = name.startswith(last) or name in ("language_model.model.embed_tokens.weight", "language_model.lm_head.weight")
+        else:
+            ok = False
+        if ok:
+            out.append(name)
+    return out
+
+
+def no_decay(name: str, shape: Tuple[int, ...]) -> bool:
+    """fsdp.py:208: `param.ndim <= 1 or name.endswith(".bias")` → weight_decay 0."""
+    return len(shape) <= 1 or name.endswith(".bias")
+
+
+@dataclass
+class Unit:
+    """One optimizer unit: a packed GEMM weight group (logical [n, k] matrix) or a plain tensor."""
+    key: str
+    offset: int                 # into the flat fp32 buffers
+    numel: int
+    group: Optional[PackedGroup]
+    dst: Optional[torch.Tensor]        # plain: contiguous bf16 view of the live parameter
+    decay: bool
+    names: Tuple[str, ...] = ()
+
+
+class ParamStore:
+    """Flat fp32 master / AdamW moments / gradients for the trainable tensors + the transposed bf16 weight copies."""
+
+    def __init__(self, w: VLAWeights, stage: str):
+        self.w, self.stage = w, stage
+        specs = w._specs()
+        names = set(trainable_names(w, stage))
+        self.names = names
+        self.units: List[Unit] = []
+        self.by_name: Dict[str, Unit] = {}
+        off = 0
+        for gi, g in enumerate(w.groups):                       # segment A: packed groups (all decayed: ndim >= 2)
+            tr = [n in names for n in g.members]
+            if not any(tr):
+                continue
+            assert all(tr), f"group {g.members} is only partly trainable"
+            u = Unit(f"group{gi}", off, g.n * g.k, g, None, True, tuple(g.members))
+            off += u.numel
+            self.units.append(u)
+            for n in g.members:
+                self.by_name[n] = u
+        self.group_numel = off
+        for name, pl in w.placements.items():                   # segment B: plain tensors
+            if pl.group is not None or name not in names:
+                continue
+            assert pl.ld == pl.cols or pl.rows == 1
+            dst = pl.dst.view(-1)[pl.offset:pl.offset + pl.rows * pl.cols]
+            u = Unit(name, off, dst.numel(), None, dst, not no_decay(name, specs[name].shape), (name,))
+            off += (u.numel + 3) // 4 * 4                       # keep 16-byte alignment of every slice
+            self.units.append(u)
+            self.by_name[name] = u
+        self.total = off
+        dev = w.embed.device
+        f = lambda: torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.master, self.m, self.v, self.grad = f(), f(), f(), f()
+        self.stage_bf16 = torch.zeros(max(self.group_numel, 8), dtype=torch.bfloat16, device=dev)
+        for u in self.units:
+            sl = self.master[u.offset:u.offset + u.numel]
+            if u.group is not None:
+                sl.view(u.group.n, u.group.k).copy_(_unpack(u.group.packed))
+            else:
+                sl.copy_(u.dst)
+        self.n_partial = 1024
+        self.partial = torch.zeros(self.n_partial, dtype=torch.float32, device=dev)
+        self.norm_coef = torch.zeros(2, dtype=torch.float32, device=dev)     # [total norm, clip coefficient]
+
+    # ---- views ----
+    def grad_view(self, name_or_unit) -> torch.Tensor:
+        """fp32 gradient of a unit: [n, k] for a group, flat for a plain tensor."""
+        u = name_or_unit if isinstance(name_or_unit, Unit) else self.by_name[name_or_unit]
+        sl = self.grad[u.offset:u.offset + u.numel]
+        return sl.view(u.group.n, u.group.k) if u.group is not None else sl
+
+    def _named(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        u, pl = self.by_name[name], self.w.placements[name]
+        shape = self.w._specs()[name].shape
+        if u.group is None:
+            return flat[u.offset:u.offset + u.numel].view(shape)
+        return _block_view(flat[u.offset:u.offset + u.numel], pl).reshape(shape)
+
+    def named_grad(self, name: str) -> torch.Tensor:
+        """Gradient under its HF name / shape (a copy for grouped tensors)."""
+        return self._named(self.grad, name)
+
+    def named_master(self, name: str) -> torch.Tensor:
+        return self._named(self.master, name)
+
+    def trainable(self, name: str) -> bool:
+        return name in self.by_name
+
+    def unit_of_packed(self, packed: torch.Tensor) -> Optional[Unit]:
+        for u in self.units:
+            if u.group is not None and u.group.packed.data_ptr() == packed.data_ptr():
+                return u
+        return None
+
+
+def transposed_pack(packed: torch.Tensor, n: int, k: int, scratch: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Packed [n, k] weight → packed [k, n] (the dgrad operand)."""
+    rm = _unpack(packed).contiguous()
+    t = torch.empty(k, n, dtype=torch.bfloat16, device=packed.device)
+    T.transpose_pad(rm, t, n)
+    return ops.pack_weight(t)
+
+
+class TrainStep:
+    """Static-shape training step for batches of B samples with L (padded) text tokens."""
+
+    def __init__(self, weights: VLAWeights, stage: str, batch: int, prompt_len: int, *, max_grad_norm: float = 1.0,
+                 weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8, store: Optional[ParamStore] = None):
+        vision, _, _ = STAGES[stage]
+        if vision:
+            raise NotImplementedError("vision-backbone backward (stages *-full-train / sandwich) is not built yet")
+        self.w, self.dims, self.stage = weights, weights.dims, stage
+        d = self.dims
+        self.B, self.L, self.S = batch, prompt_len, prompt_len + d.n_patches
+        if self.S > 320:
+            raise ValueError("training sequences are limited to 320 positions (whole-sequence attention kernels)")
+        self.max_grad_norm, self.weight_decay, self.betas, self.eps = max_grad_norm, weight_decay, betas, eps
+        self.store = store if store is not None else ParamStore(weights, stage)
+        st = self.store
+        dev = weights.embed.device
+        self.device = dev
+        B, S, D, I, V, NL = batch, self.S, d.llm_dim, d.llm_inter, d.vocab, d.llm_layers
+        Tn = B * S
+        self.T, self.Tp = Tn, (Tn + 63) // 64 * 64
+        z = lambda *shape, dtype=torch.bfloat16: torch.zeros(*shape, dtype=dtype, device=dev)
+        # ---- inputs ----
+        self.input_ids = z(B, prompt_len, dtype=torch.int64)
+        self.key_mask = torch.ones(B, S, dtype=torch.uint8, device=dev)
+        self.targets = torch.full((Tn,), IGNORE_INDEX, dtype=torch.int64, device=dev)
+        # ---- frozen vision front end: reuse the inference engine's tower plans (its LLM buffers are not allocated twice:
+        #      prompt_len 1, no decode) ----
+        from ..engine import OpenVLAEngine
+        self._vis = OpenVLAEngine(weights, batch, 1, n_new=1)
+        self.pixel_values = self._vis.pixel_values
+        self.feats = self._vis.feats
+        # ---- saved activations ----
+        Pv = 4 * d.vision_dim
+        self.z1, self.p1, self.z2, self.p2 = z(B * 256, Pv), z(B * 256, Pv), z(B * 256, D), z(B * 256, D)
+        self.x = [z(Tn, D) for _ in range(NL + 1)]            # residual stream entering layer l (x[NL] = final)
+        self.xm = [z(Tn, D) for _ in range(NL)]
+        self.h1, self.h2 = [z(Tn, D) for _ in range(NL)], [z(Tn, D) for _ in range(NL)]
+        self.qkv = [z(Tn, 3 * D) for _ in range(NL)]
+        self.ao = [z(Tn, D) for _ in range(NL)]
+        self.gu = [z(Tn, 2 * I) for _ in range(NL)]
+        self.act = [z(Tn, I) for _ in range(NL)]
+        pad = (S + 31) // 32 * 32
+        self.lse = [z(B * d.llm_heads * pad, dtype=torch.float32) for _ in range(NL)]
+        self.delta = z(B * d.llm_heads * pad, dtype=torch.float32)
+        self.hn = z(Tn, D)
+        self.logits = z(Tn, V, dtype=torch.float32)
+        self.row_loss, self.mean_cnt = z(Tn, dtype=torch.float32), z(2, dtype=torch.float32)
+        self.cos, self.sin = rope_tables(d.head_dim, d.max_pos, d.rope_theta, dev)
+        # ---- backward scratch ----
+        self.dlogits = z(Tn, V)
+        self.dxa, self.dxb, self.dh, self.dao = z(Tn, D), z(Tn, D), z(Tn, D), z(Tn, D)
+        self.dqkv, self.dgu, self.dact = z(Tn, 3 * D), z(Tn, 2 * I), z(Tn, I)
+        self.dp3, self.dp2, self.dz2, self.dp1, self.dz1 = z(B * 256, D), z(B * 256, D), z(B * 256, D), z(B * 256, Pv), z(B * 256, Pv)
+        nmax = max(V, 3 * D, 2 * I, Pv)
+        self.tA, self.tB, self.tBp = z(nmax * self.Tp), z(nmax * self.Tp), z(nmax * self.Tp)
+        self.norm_ws = z(((Tn + 63) // 64) * D, dtype=torch.float32)
+        self.col_ws = z(((Tn + 255) // 256) * max(Pv, D), dtype=torch.float32)
+        self._frozen_dw = z(max(D, Pv), dtype=torch.float32)                  # sink for norm-weight grads of frozen norms
+        # ---- transposed weights for dgrad ----
+        self._wT: Dict[int, torch.Tensor] = {}
+        self.step_count = 0
+        self.forward_ops = self._plan_forward()
+        self.backward_ops = self._plan_backward()
+        self.repack_ops = self._plan_repack()
+        self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
+
+    # ---- helpers ------------------------------------------------------------------------------------------------
+    def wT(self, packed: torch.Tensor) -> torch.Tensor:
+        """[K, N]-packed transposed copy of a packed [N, K] weight (built on first use, refreshed by repack)."""
+        key = packed.data_ptr()
+        if key not in self._wT:
+            n, k = packed.shape[0] * 16, packed.shape[1] * 32
+            self._wT[key] = transposed_pack(packed, n, k)
+        return self._wT[key]
+
+    def _dgrad(self, dy: torch.Tensor, packed: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, **kw) -> Op:
+        return ops.gemm(dy, self.wT(packed), out, epilogue, run=False, **kw)
+
+    def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, packed: torch.Tensor) -> List[Op]:
+        """dW[N, K] = dyᵀ[N, T] · x[T, K] as the NT GEMM over token-padded transposes; [] when the weight is frozen."""
+        u = self.store.unit_of_packed(packed)
+        if u is None:
+            return []
+        Tn, N = dy.shape
+        K = x.shape[1]
+        assert (N, K) == (u.group.n, u.group.k), (dy.shape, x.shape, u.group.n, u.group.k)
+        tA = self.tA[:N * self.Tp].view(N, self.Tp)
+        tB = self.tB[:K * self.Tp].view(K, self.Tp)
+        tBp = self.tBp[:K * self.Tp].view(K // 16, self.Tp // 32, 64, 8)
+        return [T.transpose_pad(dy, tA, self.Tp, run=False), T.transpose_pad(x, tB, self.Tp, run=False),
+                T.pack(tB, tBp, run=False), ops.gemm(tA, tBp, self.store.grad_view(u), EPI_F32, algo_nk=(K, Tn), run=False)]
+
+    def _gvec(self, name: str, n: int) -> torch.Tensor:
+        """fp32 gradient slot of a vector parameter, or a scratch sink when it is frozen."""
+        return self.store.grad_view(name) if self.store.trainable(name) else self._frozen_dw[:n]
+
+    # ---- plans --------------------------------------------------------------------------------------------------
+    def _plan_forward(self) -> List[Op]:
+        d, w, B, S = self.dims, self.w, self.B, self.S
+        D, H, hd = d.llm_dim, d.llm_heads, d.head_dim
+        g = lambda *a, **k: ops.gemm(*a, run=False, **k)
+        plan: List[Op] = []
+        # projector with the pre-activations kept (modeling_prismatic.py:151-156)
+        plan += [g(self.feats, w.fc1_w, self.z1, EPI_BIAS, bias=w.fc1_b), T.gelu(self.z1, self.p1, run=False),
+                 g(self.p1, w.fc2_w, self.z2, EPI_BIAS, bias=w.fc2_b), T.gelu(self.z2, self.p2, run=False),
+                 g(self.p2, w.fc3_w, self.x[0], EPI_BIAS, bias=w.fc3_b, out_map=(256, S, 1)),
+                 ops.embed_splice(self.input_ids, w.embed, self.x[0].view(B, S, D), d.n_patches, run=False)]
+        st = (S * 3 * D, hd, 3 * D)
+        for l, lw in enumerate(w.layers):
+            x, xm, qkv = self.x[l], self.xm[l], self.qkv[l]
+            plan += [ops.rmsnorm(x, lw.ln1, self.h1[l], d.rms_eps, run=False),
+                     g(self.h1[l], lw.qkv_w, qkv, EPI_NONE),
+                     T.rope(qkv, self.cos, self.sin, B=B, S=S, H=H, head_dim=hd, run=False),
+                     T.attention_lse(qkv, qkv[:, D:], qkv[:, 2 * D:], self.ao[l], self.lse[l], B=B, H=H, Sq=S, Skv=S,
+                                     head_dim=hd, q_strides=st, k_strides=st, v_strides=st, o_strides=(S * D, hd, D),
+                                     causal=True, key_mask=self.key_mask, run=False),
+                     g(self.ao[l], lw.o_w, xm, EPI_RES, res=x),
+                     ops.rmsnorm(xm, lw.ln2, self.h2[l], d.rms_eps, run=False),
+                     g(self.h2[l], lw.gu_w, self.gu[l], EPI_NONE),
+                     T.swiglu(self.gu[l], self.act[l], run=False),
+                     g(self.act[l], lw.down_w, self.x[l + 1], EPI_RES, res=xm)]
+        plan += [ops.rmsnorm(self.x[-1], w.norm, self.hn, d.rms_eps, run=False),
+                 g(self.hn, w.lm_head, self.logits, EPI_F32_BF16R),
+                 ops.cross_entropy(self.logits, self.targets, self.row_loss, self.mean_cnt, IGNORE_INDEX, run=False)]
+        return plan
+
+    def _plan_backward(self) -> List[Op]:
+        d, w, B, S, st = self.dims, self.w, self.B, self.S, self.store
+        D, H, hd = d.llm_dim, d.llm_heads, d.head_dim
+        lm = "language_model.model"
+        plan: List[Op] = [T.cross_entropy_backward(self.logits, self.targets, self.mean_cnt, self.dlogits, IGNORE_INDEX, run=False)]
+        plan += self._wgrad(self.dlogits, self.hn, w.lm_head)
+        plan.append(self._dgrad(self.dlogits, w.lm_head, self.dh))
+        dx, dx2 = self.dxa, self.dxb
+        plan.append(T.rmsnorm_backward(self.x[-1], w.norm, self.dh, dx, self._gvec(f"{lm}.norm.weight", D), self.norm_ws,
+                                       d.rms_eps, run=False))
+        strides = (S * 3 * D, hd, 3 * D)
+        stop_layer = self._lowest_needed_layer()
+        for l in range(d.llm_layers - 1, stop_layer - 1, -1):
+            lw, b = w.layers[l], f"{lm}.layers.{l}"
+            plan += self._wgrad(dx, self.act[l], lw.down_w)
+            plan.append(self._dgrad(dx, lw.down_w, self.dact))
+            plan.append(T.swiglu_backward(self.gu[l], self.dact, self.dgu, run=False))
+            plan += self._wgrad(self.dgu, self.h2[l], lw.gu_w)
+            plan.append(self._dgrad(self.dgu, lw.gu_w, self.dh))
+            plan.append(T.rmsnorm_backward(self.xm[l], lw.ln2, self.dh, dx2, self._gvec(f"{b}.post_attention_layernorm.weight", D),
+                                           self.norm_ws, d.rms_eps, dres=dx, run=False))
+            plan += self._wgrad(dx2, self.ao[l], lw.o_w)
+            plan.append(self._dgrad(dx2, lw.o_w, self.dao))
+            qkv, dq = self.qkv[l], self.dqkv
+            plan.append(T.attention_backward(qkv, qkv[:, D:], qkv[:, 2 * D:], self.ao[l], self.dao, self.lse[l], self.delta,
+                                             dq, dq[:, D:], dq[:, 2 * D:], B=B, H=H, Sq=S, Skv=S, head_dim=hd,
+                                             q_strides=strides, k_strides=strides, v_strides=strides,
+                                             o_strides=(S * D, hd, D), causal=True, key_mask=self.key_mask, run=False))
+            plan.append(T.rope_backward(dq, self.cos, self.sin, B=B, S=S, H=H, head_dim=hd, run=False))
+            plan += self._wgrad(dq, self.h1[l], lw.qkv_w)
+            plan.append(self._dgrad(dq, lw.qkv_w, self.dh))
+            plan.append(T.rmsnorm_backward(self.x[l], lw.ln1, self.dh, dx, self._gvec(f"{b}.input_layernorm.weight", D),
+                                           self.norm_ws, d.rms_eps, dres=dx2, run=False))
+        if stop_layer > 0:
+            return plan
+        # dx = gradient of inputs_embeds [B, S, D]
+        if st.trainable(f"{lm}.embed_tokens.weight"):
+            plan.append(T.embed_backward(self.input_ids, dx.view(B, S, D), st.grad_view(f"{lm}.embed_tokens.weight").view(d.vocab, D),
+                                         d.n_patches, run=False))
+        if st.trainable("projector.fc3.weight"):
+            plan.append(T.map_rows(dx, self.dp3, rows=B * 256, group=256, stride=S, offset=1, scatter=False, run=False))
+            plan.append(T.colsum(self.dp3, st.grad_view("projector.fc3.bias"), self.col_ws, run=False))
+            plan += self._wgrad(self.dp3, self.p2, w.fc3_w)
+            plan.append(self._dgrad(self.dp3, w.fc3_w, self.dp2))
+            plan.append(T.gelu_backward(self.z2, self.dp2, self.dz2, run=False))
+            plan.append(T.colsum(self.dz2, st.grad_view("projector.fc2.bias"), self.col_ws, run=False))
+            plan += self._wgrad(self.dz2, self.p1, w.fc2_w)
+            plan.append(self._dgrad(self.dz2, w.fc2_w, self.dp1))
+            plan.append(T.gelu_backward(self.z1, self.dp1, self.dz1, run=False))
+            plan.append(T.colsum(self.dz1, st.grad_view("projector.fc1.bias"), self.col_ws, run=False))
+            plan += self._wgrad(self.dz1, self.feats, w.fc1_w)
+        return plan
+
+    def _lowest_needed_layer(self) -> int:
+        """Backward stops above the lowest decoder layer that still has a trainable tensor below or inside it."""
+        names = self.store.names
+        if any(not n.startswith("language_model.model.layers.") and not n.startswith("language_model.lm_head")
+               and not n.startswith("language_model.model.norm") for n in names):
+            return 0                     # embeddings / projector / vision sit under layer 0
+        lows = [int(n.split(".")[3]) for n in names if n.startswith("language_model.model.layers.")]
+        return min(lows) if lows else self.dims.llm_layers
+
+    def _plan_repack(self) -> List[Op]:
+        """After AdamW wrote the bf16 copy of every group's logical matrix: refresh the forward and the dgrad layouts."""
+        plan: List[Op] = []
+        st = self.store
+        nmax = max((u.numel for u in st.units if u.group is not None), default=8)
+        self._tW = torch.zeros(nmax, dtype=torch.bfloat16, device=self.device)
+        for u in st.units:
+            if u.group is None:
+                continue
+            n, k = u.group.n, u.group.k
+            rm = st.stage_bf16[u.offset:u.offset + u.numel].view(n, k)
+            plan.append(T.pack(rm, u.group.packed, run=False))
+            key = u.group.packed.data_ptr()
+            if key in self._wT:                                   # only weights that a dgrad GEMM actually reads
+                tw = self._tW[:n * k].view(k, n)
+                plan += [T.transpose_pad(rm, tw, n, run=False), T.pack(tw, self._wT[key], run=False)]
+        return plan
+
+    # ---- running ------------------------------------------------------------------------------------------------
+    def set_batch(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], pixel_values: torch.Tensor,
+                  labels: torch.Tensor) -> None:
+        """Right-padded batch (PaddedCollatorForActionPrediction, data_utils.py:101-142) → static device inputs. Batches
+        shorter than the planned L are padded further (pad id 32000 / mask 0 / label -100: no effect on valid rows)."""
+        dev, B, L, P, S = self.device, self.B, self.L, self.dims.n_patches, self.S
+        b, l = input_ids.shape
+        if b != B or l > L:
+            raise ValueError(f"batch {tuple(input_ids.shape)} does not fit the planned step ({B}, <= {L})")
+        ids = torch.full((B, L), 32000, dtype=torch.int64, device=dev)
+        ids[:, :l] = input_ids.to(dev)
+        m = torch.zeros(B, L, dtype=torch.uint8, device=dev)
+        m[:, :l] = (attention_mask.to(dev) if attention_mask is not None else torch.ones(b, l, device=dev)).to(torch.uint8)
+        lab = torch.full((B, L), IGNORE_INDEX, dtype=torch.int64, device=dev)
+        lab[:, :l] = labels.to(dev)
+        self.input_ids.copy_(ids)
+        self.pixel_values.copy_(pixel_values.to(dev).to(torch.bfloat16))
+        self.key_mask[:, :1] = m[:, :1]
+        self.key_mask[:, 1:1 + P] = 1
+        self.key_mask[:, 1 + P:] = m[:, 1:]
+        full = torch.full((B, S), IGNORE_INDEX, dtype=torch.int64, device=dev)       # labels with 256 ignored patch columns
+        full[:, :1] = lab[:, :1]
+        full[:, 1 + P:] = lab[:, 1:]
+        tg = torch.full((B, S), IGNORE_INDEX, dtype=torch.int64, device=dev)
+        tg[:, :-1] = full[:, 1:]                                                       # position t predicts token t+1
+        self.targets.copy_(tg.view(-1))
+
+    def _replay(self, key: str, plan: List[Op], graph: bool) -> None:
+        if not graph:
+            ops.run_all(plan)
+            return
+        gr = self._graphs.get(key)
+        if gr is None:
+            ops.run_all(plan)                                      # warm (lazy hipFuncSetAttribute etc.) outside capture
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                ops.run_all(plan)
+            self._graphs[key] = gr
+        gr.replay()
+
+    def forward(self, graph: bool = False) -> torch.Tensor:
+        """Vision towers (frozen) → projector → decoder → loss. Returns the device scalar loss."""
+        self._vis.run_vision()
+        self._replay("fwd", self.forward_ops, graph)
+        return self.mean_cnt[0]
+
+    def backward(self, graph: bool = False) -> None:
+        emb = "language_model.model.embed_tokens.weight"
+        if self.store.trainable(emb):
+            self.store.grad_view(emb).zero_()                      # accumulated with atomics
+        self._replay("bwd", self.backward_ops, graph)
+
+    def clip_grad_norm(self) -> torch.Tensor:
+        """Global L2 norm over every trainable gradient + clip coefficient min(1, max_norm / (norm + 1e-6)), kept on
+        the device (fsdp.py:238-240 → FSDP.clip_grad_norm_). Returns the device scalar total norm."""
+        st = self.store
+        T.sumsq_partial(st.grad, st.partial)
+        T.clip_coef(st.partial, self.max_grad_norm, st.norm_coef)
+        return st.norm_coef[0]
+
+    def optimizer_step(self, lr: float, graph: bool = False) -> None:
+        """AdamW on the fp32 masters (decay groups per fsdp.py:200-212), bf16 copies re-packed for the next forward."""
+        st = self.store
+        self.step_count += 1
+        kw = dict(betas=self.betas, eps=self.eps, norm_coef=st.norm_coef)
+        if st.group_numel:
+            n = st.group_numel
+            T.adamw(st.master[:n], st.m[:n], st.v[:n], st.grad[:n], self.step_count, lr, weight_decay=self.weight_decay,
+                    p_bf16=st.stage_bf16, **kw)
+        for u in st.units:
+            if u.group is None:
+                sl = slice(u.offset, u.offset + u.numel)
+                T.adamw(st.master[sl], st.m[sl], st.v[sl], st.grad[sl], self.step_count, lr,
+                        weight_decay=self.weight_decay if u.decay else 0.0, p_bf16=u.dst, **kw)
+        self._replay("repack", self.repack_ops, graph)
+
+    def step(self, lr: float, graph: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        """forward → backward → clip → AdamW. Returns (loss, grad norm) as device scalars (no host sync here)."""
+        loss = self.forward(graph)
+        self.backward(graph)
+        norm = self.clip_grad_norm()
+        self.optimizer_step(lr, graph)
+        return loss, norm

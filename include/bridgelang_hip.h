@@ -139,6 +139,10 @@ int bl_attention_backward_bf16(const bl_attn_desc* d, const bl_bf16* dout, const
 /* Single-query decode attention over a KV cache; kv_len = number of valid keys (same for the whole batch). */
 int bl_attention_decode_bf16(const bl_attn_desc* d, void* stream);
 
+/* Training forward: rotate q and k of the fused qkv rows IN PLACE (same arithmetic as bl_rope_kvcache_bf16, no cache). */
+int bl_rope_bf16(bl_bf16* qkv, int32_t B, int32_t S, int32_t H, int32_t head_dim, const bl_bf16* cos_tab,
+                 const bl_bf16* sin_tab, int32_t pos0, void* stream);
+
 /* Decode attention with the rotary embedding and the KV-cache append of the NEW token fused in: q / k_new / v_new are
  * the three thirds of the step's fused qkv row (strides d->q_*; k_new = q + H*hd, v_new = q + 2*H*hd elements). q and
  * k_new are rotated at position `pos` (HF apply_rotary_pos_emb, bf16 roundings as bl_rope_kvcache_bf16), k_new', v_new
@@ -203,6 +207,11 @@ int bl_clip_coef_f32(const float* partial, int32_t n, float max_norm, float* out
  * (optional) receives the bf16 copy of the updated weights. */
 int bl_adamw_f32(float* p, float* m, float* v, const float* g, const float* norm_coef, int64_t n, float lr, float beta1,
                  float beta2, float eps, float weight_decay, int32_t step, bl_bf16* p_bf16, void* stream);
+/* Row gather (scatter = 0: dst[r] = src[map(r)]) or scatter (dst[map(r)] = src[r]) with
+ * map(r) = (r / group) * stride + offset + r % group — the 256 projected patch rows inside the [B, S, D] embedding
+ * buffer (modeling_prismatic.py:343-351) for the projector's backward. */
+int bl_map_rows_bf16(const bl_bf16* src, int64_t ld_src, bl_bf16* dst, int64_t ld_dst, int64_t rows, int32_t cols,
+                     int32_t group, int32_t stride, int32_t offset, int32_t scatter, void* stream);
 /* dW_embed[ids[b,j]] += dx[b, row(j)] over the text positions of the multimodal splice (fp32 atomics; dw pre-zeroed). */
 int bl_embed_backward_bf16(const int64_t* ids, int32_t B, int32_t L, const bl_bf16* dx, int32_t dim, int32_t n_patches,
                            float* dw, void* stream);

@@ -1,0 +1,118 @@
+"""The training step (forward with saved activations → hand-written backward → clip → AdamW) against torch.autograd and
+torch.optim.AdamW over the CPU oracle, reduced-width model, reference stage semantics (prismatic.py:129-241)."""
+import pytest
+import torch
+
+from conftest import rand_bf16
+from oracle import restate as R
+
+pytestmark = pytest.mark.gpu
+
+
+def make_batch(dims, B, L, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(3, 31000, (B, L), generator=g)
+    ids[:, 0] = 1
+    lens = [L - 3 * i for i in range(B)]
+    mask = torch.zeros(B, L, dtype=torch.bool)
+    labels = torch.full((B, L), -100)
+    for i, n in enumerate(lens):
+        mask[i, :n] = True
+        ids[i, n:] = 32000
+        ids[i, n - 8:n - 1] = torch.randint(31744, 32000, (7,), generator=g)     # action tokens
+        ids[i, n - 1] = 2
+        labels[i, n - 8:n] = ids[i, n - 8:n]                                     # datasets.py:63
+    pv = rand_bf16((B, 6, 224, 224), seed + 1)
+    return ids, mask, labels, pv
+
+
+def oracle_loss(sd, dims, ids, mask, labels, pv):
+    om = R.OracleModel.from_dims(sd, dims)
+    logits, _, _ = om.prefill(ids, pv, attention_mask=mask)
+    B = ids.shape[0]
+    full = torch.cat([labels[:, :1], torch.full((B, 256), -100), labels[:, 1:]], 1)
+    return torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, dims.vocab), full[:, 1:].reshape(-1), ignore_index=-100)
+
+
+def cos(a, b):
+    a, b = a.flatten().double(), b.flatten().double()
+    return (a @ b / (a.norm() * b.norm() + 1e-300)).item()
+
+
+@pytest.mark.parametrize("stage", ["vla-train", "vla-last-layer-train", "align"])
+def test_gradients_match_autograd(dev, stage):
+    from bridgelang_amd.training.step import TrainStep, trainable_names
+    from bridgelang_amd.weights import allocate, tiny_dims
+    dims = tiny_dims()
+    w = allocate(dims, dev).fill_synthetic(seed=3)
+    sd = {k: v.float().cpu() for k, v in w.state_dict().items()}
+    B, L = 3, 20
+    ids, mask, labels, pv = make_batch(dims, B, L)
+    ts = TrainStep(w, stage, B, L + 2)                      # planned longer than the batch: extra right padding
+    ts.set_batch(ids, mask, pv, labels)
+    loss = ts.forward()
+    ts.backward()
+    names = trainable_names(w, stage)
+    for n in names:
+        sd[n].requires_grad_(True)
+    ref = oracle_loss(sd, dims, ids, mask, labels, pv)
+    ref.backward()
+    print(f"[{stage}] loss {loss.item():.5f} vs oracle {ref.item():.5f}; {len(names)} trainable tensors")
+    assert abs(loss.item() - ref.item()) <= 2e-3 * abs(ref.item())
+    worst = 1.0
+    for n in names:
+        got, want = ts.store.named_grad(n).float().cpu(), sd[n].grad
+        scale = want.abs().max().item()
+        assert scale > 0, n
+        c = cos(got, want)
+        worst = min(worst, c)
+        err = (got - want).abs().max().item()
+        assert c > 0.99 and err <= 0.06 * scale, f"{n}: cosine {c:.5f}, max err {err:.3g} vs scale {scale:.3g}"
+    print(f"[{stage}] worst gradient cosine {worst:.5f}")
+    frozen = [n for n in sd if n not in names]
+    assert all(not ts.store.trainable(n) for n in frozen)
+
+
+def test_two_steps_match_torch_adamw(dev):
+    """clip_grad_norm(1.0) + AdamW (decay on matrices, none on norms / biases — fsdp.py:200-212) for two steps; the
+    second forward runs on the re-packed updated weights, so its loss checks the whole update path."""
+    from bridgelang_amd.training.step import TrainStep, trainable_names, no_decay
+    from bridgelang_amd.weights import allocate, tiny_dims
+    dims = tiny_dims()
+    w = allocate(dims, dev).fill_synthetic(seed=5)
+    sd = {k: v.float().cpu() for k, v in w.state_dict().items()}
+    B, L, lr, wd = 2, 18, 2e-4, 0.1
+    ts = TrainStep(w, "vla-train", B, L, max_grad_norm=1.0, weight_decay=wd)
+    names = trainable_names(w, "vla-train")
+    params = {n: sd[n].clone().requires_grad_(True) for n in names}
+    opt = torch.optim.AdamW([{"params": [params[n] for n in names if not no_decay(n, params[n].shape)], "weight_decay": wd},
+                             {"params": [params[n] for n in names if no_decay(n, params[n].shape)], "weight_decay": 0.0}], lr=lr)
+    for step in range(2):
+        ids, mask, labels, pv = make_batch(dims, B, L, seed=10 + step)
+        ts.set_batch(ids, mask, pv, labels)
+        loss, norm = ts.step(lr, graph=(step == 1))
+        # oracle: bf16 compute copy of the fp32 masters (FSDP MixedPrecision param_dtype=bf16, fsdp.py:141-147)
+        sd_step = dict(sd)
+        bf = {n: params[n].detach().to(torch.bfloat16).float().requires_grad_(True) for n in names}
+        sd_step.update(bf)
+        ref = oracle_loss(sd_step, dims, ids, mask, labels, pv)
+        ref.backward()
+        for n in names:
+            params[n].grad = bf[n].grad
+        ref_norm = torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+        opt.step()
+        opt.zero_grad()
+        print(f"step {step}: loss {loss.item():.5f} vs {ref.item():.5f}; grad norm {norm.item():.4f} vs {ref_norm.item():.4f}")
+        assert abs(loss.item() - ref.item()) <= 3e-3 * abs(ref.item())
+        assert abs(norm.item() - ref_norm.item()) <= 2e-2 * ref_norm.item()
+    # parameter movement: same direction and size as torch's AdamW
+    for n in names:
+        got = ts.store.named_master(n).float().cpu() - sd[n]
+        want = params[n].detach() - sd[n]
+        c = cos(got, want)
+        assert c > 0.97, f"{n}: update cosine {c:.4f}"
+        assert abs(got.norm().item() - want.norm().item()) <= 0.05 * want.norm().item(), n
+    # the live bf16 weights are the rounded masters
+    live = w.state_dict()
+    for n in names:
+        assert torch.equal(live[n].float().cpu(), ts.store.named_master(n).to(torch.bfloat16).float().cpu()), n
