@@ -287,18 +287,37 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const uint16_t* in, 
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, long n, float* partial) {
   __shared__ float red[4];
   float s = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += g[i] * g[i];
+  if ((((uintptr_t)g) & 15) == 0) {        // 16-byte loads, four independent accumulation chains per thread
+    const long n4 = n >> 2;
+    const f32x4_t* g4 = (const f32x4_t*)g;
+    f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+      const f32x4_t t = __builtin_nontemporal_load(g4 + i);
+      a += t * t;
+    }
+    s = (a[0] + a[1]) + (a[2] + a[3]);
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += g[i] * g[i];
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += g[i] * g[i];
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 // total norm + clip coefficient (torch.nn.utils.clip_grad_norm_: coef = clamp(max_norm / (norm + 1e-6), max = 1))
-__global__ void clip_coef_kernel(const float* partial, int n, float max_norm, float* out_norm_coef) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void clip_coef_kernel(const float* partial, int n, float max_norm, float* out_norm_coef) {
+  __shared__ double red[256];
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += (double)partial[i];
-  const float norm = (float)sqrt(s);
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const float norm = (float)sqrt(red[0]);
   out_norm_coef[0] = norm;
   out_norm_coef[1] = fminf(1.0f, max_norm / (norm + 1e-6f));
 }
@@ -468,7 +487,7 @@ extern "C" int bl_sumsq_partial_f32(const float* g, int64_t n, float* partial, i
 extern "C" int bl_clip_coef_f32(const float* partial, int32_t n, float max_norm, float* out_norm_coef, void* stream) {
   if (!partial || !out_norm_coef) return BL_E_ARG;
   if (n <= 0) return BL_E_SHAPE;
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, n, max_norm, out_norm_coef);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, max_norm, out_norm_coef);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

@@ -26,6 +26,7 @@ from .. import ops, train_ops as T
 from ..engine import rope_tables
 from ..ops import EPI_BIAS, EPI_F32, EPI_F32_BF16R, EPI_NONE, EPI_RES, Op
 from ..weights import PackedGroup, Placement, VLAWeights, _block_view, _unpack
+from .sharding import ShardComm, ShardLayout, bucket_key, comm_order
 
 IGNORE_INDEX = -100
 
@@ -72,58 +73,78 @@ def no_decay(name: str, shape: Tuple[int, ...]) -> bool:
 class Unit:
     """One optimizer unit: a packed GEMM weight group (logical [n, k] matrix) or a plain tensor."""
     key: str
-    offset: int                 # into the flat fp32 buffers
+    offset: int                 # into the flat (bucket-padded) parameter space
     numel: int
     group: Optional[PackedGroup]
     dst: Optional[torch.Tensor]        # plain: contiguous bf16 view of the live parameter
     decay: bool
+    bucket: int
     names: Tuple[str, ...] = ()
 
 
 class ParamStore:
-    """Flat fp32 master / AdamW moments / gradients for the trainable tensors + the transposed bf16 weight copies."""
+    """Trainable tensors as one flat parameter space (sharding.ShardLayout): full fp32 gradients and a full bf16 staging
+    copy on every rank, fp32 masters and AdamW moments for this rank's 1/world slice of every bucket only."""
 
-    def __init__(self, w: VLAWeights, stage: str):
+    def __init__(self, w: VLAWeights, stage: str, world: int = 1, rank: int = 0):
         self.w, self.stage = w, stage
         specs = w._specs()
         names = set(trainable_names(w, stage))
         self.names = names
         self.units: List[Unit] = []
         self.by_name: Dict[str, Unit] = {}
-        off = 0
-        for gi, g in enumerate(w.groups):                       # segment A: packed groups (all decayed: ndim >= 2)
+        self.layout = lay = ShardLayout(world, rank)
+        cur = None
+        for gi, g in enumerate(w.groups):                       # GEMM weight groups (all decayed: ndim >= 2)
             tr = [n in names for n in g.members]
             if not any(tr):
                 continue
             assert all(tr), f"group {g.members} is only partly trainable"
-            u = Unit(f"group{gi}", off, g.n * g.k, g, None, True, tuple(g.members))
-            off += u.numel
+            key = bucket_key(g.members[0])
+            if key != cur:
+                lay.begin(key, True)
+                cur = key
+            u = Unit(f"group{gi}", 0, g.n * g.k, g, None, True, len(lay.buckets) - 1, tuple(g.members))
+            u.offset = lay.add(u.numel, len(self.units))
             self.units.append(u)
             for n in g.members:
                 self.by_name[n] = u
-        self.group_numel = off
-        for name, pl in w.placements.items():                   # segment B: plain tensors
-            if pl.group is not None or name not in names:
+        for decay in (True, False):                             # plain tensors: one bucket per weight-decay class
+            todo = [(n, pl) for n, pl in w.placements.items() if pl.group is None and n in names
+                    and (not no_decay(n, specs[n].shape)) == decay]
+            if not todo:
                 continue
-            assert pl.ld == pl.cols or pl.rows == 1
-            dst = pl.dst.view(-1)[pl.offset:pl.offset + pl.rows * pl.cols]
-            u = Unit(name, off, dst.numel(), None, dst, not no_decay(name, specs[name].shape), (name,))
-            off += (u.numel + 3) // 4 * 4                       # keep 16-byte alignment of every slice
-            self.units.append(u)
-            self.by_name[name] = u
-        self.total = off
+            lay.begin("plain.decay" if decay else "plain.nodecay", decay)
+            for name, pl in todo:
+                assert pl.ld == pl.cols or pl.rows == 1
+                dst = pl.dst.view(-1)[pl.offset:pl.offset + pl.rows * pl.cols]
+                u = Unit(name, 0, dst.numel(), None, dst, decay, len(lay.buckets) - 1, (name,))
+                u.offset = lay.add(u.numel, len(self.units))
+                self.units.append(u)
+                self.by_name[name] = u
+        lay.close()
+        self.total = lay.total
+        self.n_params = sum(u.numel for u in self.units)
         dev = w.embed.device
-        f = lambda: torch.zeros(self.total, dtype=torch.float32, device=dev)
-        self.master, self.m, self.v, self.grad = f(), f(), f(), f()
-        self.stage_bf16 = torch.zeros(max(self.group_numel, 8), dtype=torch.bfloat16, device=dev)
-        for u in self.units:
-            sl = self.master[u.offset:u.offset + u.numel]
-            if u.group is not None:
-                sl.view(u.group.n, u.group.k).copy_(_unpack(u.group.packed))
-            else:
-                sl.copy_(u.dst)
-        self.n_partial = 1024
-        self.partial = torch.zeros(self.n_partial, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(max(lay.total, 8), dtype=torch.float32, device=dev)
+        self.stage_bf16 = torch.zeros(max(lay.total, 8), dtype=torch.bfloat16, device=dev)
+        f = lambda: torch.zeros(max(lay.local_total, 8), dtype=torch.float32, device=dev)
+        self.master, self.m, self.v = f(), f(), f()
+        for bi, b in enumerate(lay.buckets):                    # masters ← this rank's slice of the live bf16 weights
+            full = torch.zeros(b.numel, dtype=torch.float32, device=dev)
+            for ui in b.members:
+                u = self.units[ui]
+                sl = full[u.offset - b.offset:u.offset - b.offset + u.numel]
+                if u.group is not None:
+                    sl.view(u.group.n, u.group.k).copy_(_unpack(u.group.packed))
+                else:
+                    sl.copy_(u.dst)
+            lo, hi = lay.shard_range(b)
+            lo_l = lay.local_offset(b)
+            self.master[lo_l:lo_l + hi - lo].copy_(full[lo - b.offset:hi - b.offset])
+            del full
+        self.blocks_per_bucket = 256
+        self.partial = torch.zeros(self.blocks_per_bucket * max(len(lay.buckets), 1), dtype=torch.float32, device=dev)
         self.norm_coef = torch.zeros(2, dtype=torch.float32, device=dev)     # [total norm, clip coefficient]
 
     # ---- views ----
@@ -141,11 +162,19 @@ class ParamStore:
         return _block_view(flat[u.offset:u.offset + u.numel], pl).reshape(shape)
 
     def named_grad(self, name: str) -> torch.Tensor:
-        """Gradient under its HF name / shape (a copy for grouped tensors)."""
+        """Local (un-reduced) gradient under its HF name / shape (a copy for grouped tensors)."""
         return self._named(self.grad, name)
 
-    def named_master(self, name: str) -> torch.Tensor:
-        return self._named(self.master, name)
+    def full_master(self, comm: Optional[ShardComm] = None) -> torch.Tensor:
+        """All fp32 masters in the flat layout (gathered over ranks when sharded) — checkpoints and tests."""
+        return (comm or ShardComm(self.layout)).gather_full(self.master)
+
+    def named_master(self, name: str, full: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self._named(self.full_master() if full is None else full, name)
+
+    def master_state_dict(self, comm: Optional[ShardComm] = None) -> Dict[str, torch.Tensor]:
+        full = self.full_master(comm)
+        return {n: self._named(full, n).clone() for n in self.by_name}
 
     def trainable(self, name: str) -> bool:
         return name in self.by_name
@@ -169,7 +198,8 @@ class TrainStep:
     """Static-shape training step for batches of B samples with L (padded) text tokens."""
 
     def __init__(self, weights: VLAWeights, stage: str, batch: int, prompt_len: int, *, max_grad_norm: float = 1.0,
-                 weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8, store: Optional[ParamStore] = None):
+                 weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8, store: Optional[ParamStore] = None,
+                 world: int = 1, rank: int = 0, group=None, reduce_dtype: torch.dtype = torch.float32):
         vision, _, _ = STAGES[stage]
         if vision:
             raise NotImplementedError("vision-backbone backward (stages *-full-train / sandwich) is not built yet")
@@ -179,8 +209,10 @@ class TrainStep:
         if self.S > 320:
             raise ValueError("training sequences are limited to 320 positions (whole-sequence attention kernels)")
         self.max_grad_norm, self.weight_decay, self.betas, self.eps = max_grad_norm, weight_decay, betas, eps
-        self.store = store if store is not None else ParamStore(weights, stage)
+        self.store = store if store is not None else ParamStore(weights, stage, world, rank)
         st = self.store
+        self.comm = ShardComm(st.layout, group, reduce_dtype)
+        self.world = st.layout.world
         dev = weights.embed.device
         self.device = dev
         B, S, D, I, V, NL = batch, self.S, d.llm_dim, d.llm_inter, d.vocab, d.llm_layers
@@ -228,9 +260,11 @@ class TrainStep:
         self._wT: Dict[int, torch.Tensor] = {}
         self.step_count = 0
         self.forward_ops = self._plan_forward()
+        self._ready: List[Tuple[int, str]] = []      # (number of backward ops enqueued, bucket key complete at that point)
         self.backward_ops = self._plan_backward()
         self.repack_ops = self._plan_repack()
         self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
+        self._comm_stream = torch.cuda.Stream(device=dev) if self.comm.active else None
 
     # ---- helpers ------------------------------------------------------------------------------------------------
     def wT(self, packed: torch.Tensor) -> torch.Tensor:
@@ -298,6 +332,7 @@ class TrainStep:
         lm = "language_model.model"
         plan: List[Op] = [T.cross_entropy_backward(self.logits, self.targets, self.mean_cnt, self.dlogits, IGNORE_INDEX, run=False)]
         plan += self._wgrad(self.dlogits, self.hn, w.lm_head)
+        self._ready.append((len(plan), "llm.lm_head"))
         plan.append(self._dgrad(self.dlogits, w.lm_head, self.dh))
         dx, dx2 = self.dxa, self.dxb
         plan.append(T.rmsnorm_backward(self.x[-1], w.norm, self.dh, dx, self._gvec(f"{lm}.norm.weight", D), self.norm_ws,
@@ -322,6 +357,7 @@ class TrainStep:
                                              o_strides=(S * D, hd, D), causal=True, key_mask=self.key_mask, run=False))
             plan.append(T.rope_backward(dq, self.cos, self.sin, B=B, S=S, H=H, head_dim=hd, run=False))
             plan += self._wgrad(dq, self.h1[l], lw.qkv_w)
+            self._ready.append((len(plan), f"llm.layer{l:02d}"))
             plan.append(self._dgrad(dq, lw.qkv_w, self.dh))
             plan.append(T.rmsnorm_backward(self.x[l], lw.ln1, self.dh, dx, self._gvec(f"{b}.input_layernorm.weight", D),
                                            self.norm_ws, d.rms_eps, dres=dx2, run=False))
@@ -343,6 +379,7 @@ class TrainStep:
             plan.append(T.gelu_backward(self.z1, self.dp1, self.dz1, run=False))
             plan.append(T.colsum(self.dz1, st.grad_view("projector.fc1.bias"), self.col_ws, run=False))
             plan += self._wgrad(self.dz1, self.feats, w.fc1_w)
+            self._ready.append((len(plan), "projector"))
         return plan
 
     def _lowest_needed_layer(self) -> int:
@@ -360,6 +397,7 @@ class TrainStep:
         st = self.store
         nmax = max((u.numel for u in st.units if u.group is not None), default=8)
         self._tW = torch.zeros(nmax, dtype=torch.bfloat16, device=self.device)
+        self._plain_copies = [(u.dst, st.stage_bf16[u.offset:u.offset + u.numel]) for u in st.units if u.group is None]
         for u in st.units:
             if u.group is None:
                 continue
@@ -420,33 +458,72 @@ class TrainStep:
         return self.mean_cnt[0]
 
     def backward(self, graph: bool = False) -> None:
+        """Hand-written backward into the flat fp32 gradient buffer. Sharded runs (world > 1) issue each bucket's
+        reduce-scatter on a side stream as soon as its last wgrad is enqueued (overlapping the rest of the backward)."""
+        st, lay = self.store, self.store.layout
         emb = "language_model.model.embed_tokens.weight"
-        if self.store.trainable(emb):
-            self.store.grad_view(emb).zero_()                      # accumulated with atomics
-        self._replay("bwd", self.backward_ops, graph)
+        if st.trainable(emb):
+            st.grad_view(emb).zero_()                              # accumulated with atomics
+        if not self.comm.active:
+            self._replay("bwd", self.backward_ops, graph)
+            return
+        self.mean_cnt[1].mul_(self.world)                          # dlogits / world: the SUM over ranks is the DDP mean
+        main = torch.cuda.current_stream()
+        by_key = {b.key: b for b in lay.buckets}
+        done, reduced = 0, set()
+
+        def reduce(b):
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self._comm_stream.wait_event(ev)
+            with torch.cuda.stream(self._comm_stream):
+                self.comm.reduce_scatter_grads(st.grad, b, st.stage_bf16[b.offset:b.offset + b.numel])
+            reduced.add(b.key)
+        for upto, key in self._ready:
+            ops.run_all(self.backward_ops[done:upto])
+            done = upto
+            if key in by_key:
+                reduce(by_key[key])
+        ops.run_all(self.backward_ops[done:])
+        for i in comm_order(lay.buckets):                          # whatever has no marker (plain tensors) goes last
+            if lay.buckets[i].key not in reduced:
+                reduce(lay.buckets[i])
+        main.wait_stream(self._comm_stream)
 
     def clip_grad_norm(self) -> torch.Tensor:
         """Global L2 norm over every trainable gradient + clip coefficient min(1, max_norm / (norm + 1e-6)), kept on
-        the device (fsdp.py:238-240 → FSDP.clip_grad_norm_). Returns the device scalar total norm."""
-        st = self.store
-        T.sumsq_partial(st.grad, st.partial)
+        the device (fsdp.py:238-240 → FSDP.clip_grad_norm_). Each rank sums its own slices; the partial sums are
+        all-reduced. Returns the device scalar total norm."""
+        st, lay, nb = self.store, self.store.layout, self.store.blocks_per_bucket
+        for i, b in enumerate(lay.buckets):
+            lo, hi = lay.shard_range(b)
+            T.sumsq_partial(st.grad[lo:hi], st.partial[i * nb:(i + 1) * nb])
+        self.comm.all_reduce_sum(st.partial)
         T.clip_coef(st.partial, self.max_grad_norm, st.norm_coef)
         return st.norm_coef[0]
 
     def optimizer_step(self, lr: float, graph: bool = False) -> None:
-        """AdamW on the fp32 masters (decay groups per fsdp.py:200-212), bf16 copies re-packed for the next forward."""
-        st = self.store
+        """AdamW on this rank's slice of the fp32 masters (decay classes per fsdp.py:200-212), all-gather of the updated
+        bf16 slices, re-pack into the forward / dgrad layouts."""
+        st, lay = self.store, self.store.layout
         self.step_count += 1
-        kw = dict(betas=self.betas, eps=self.eps, norm_coef=st.norm_coef)
-        if st.group_numel:
-            n = st.group_numel
-            T.adamw(st.master[:n], st.m[:n], st.v[:n], st.grad[:n], self.step_count, lr, weight_decay=self.weight_decay,
-                    p_bf16=st.stage_bf16, **kw)
-        for u in st.units:
-            if u.group is None:
-                sl = slice(u.offset, u.offset + u.numel)
-                T.adamw(st.master[sl], st.m[sl], st.v[sl], st.grad[sl], self.step_count, lr,
-                        weight_decay=self.weight_decay if u.decay else 0.0, p_bf16=u.dst, **kw)
+        main = torch.cuda.current_stream()
+        for i in comm_order(lay.buckets):
+            b = lay.buckets[i]
+            lo, hi = lay.shard_range(b)
+            sl = slice(lay.local_offset(b), lay.local_offset(b) + hi - lo)
+            T.adamw(st.master[sl], st.m[sl], st.v[sl], st.grad[lo:hi], self.step_count, lr, betas=self.betas, eps=self.eps,
+                    weight_decay=self.weight_decay if b.decay else 0.0, norm_coef=st.norm_coef, p_bf16=st.stage_bf16[lo:hi])
+            if self.comm.active:                                   # gather bucket i while AdamW runs on bucket i+1
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self._comm_stream.wait_event(ev)
+                with torch.cuda.stream(self._comm_stream):
+                    self.comm.all_gather_params(st.stage_bf16, b)
+        if self.comm.active:
+            main.wait_stream(self._comm_stream)
+        for dst, src in self._plain_copies:
+            dst.copy_(src)
         self._replay("repack", self.repack_ops, graph)
 
     def step(self, lr: float, graph: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -1,0 +1,95 @@
+"""Sharded training step end to end on one GPU box: two ranks (two processes on cuda:0, gloo moving the CUDA tensors —
+RCCL refuses two ranks on one device) each run the step on their half of the batch with the optimizer state sharded;
+the result must match a single process stepping on the whole batch (DDP mean of per-rank mean losses = global mean,
+every sample carries 8 supervised tokens)."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+from test_train_step_gpu import make_batch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+_WORKER = r'''
+import os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["BL_ROOT"]); sys.path.insert(0, os.path.join(os.environ["BL_ROOT"], "tests"))
+from test_train_step_gpu import make_batch
+from bridgelang_amd.training.step import TrainStep
+from bridgelang_amd.weights import allocate, tiny_dims
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+dev = torch.device("cuda:0")
+dims = tiny_dims()
+w = allocate(dims, dev).fill_synthetic(seed=3)
+B, L = 4, 20
+rd = torch.bfloat16 if os.environ.get("BL_REDUCE") == "bf16" else torch.float32
+ts = TrainStep(w, "vla-train", B // world, L, max_grad_norm=1.0, weight_decay=0.1, world=world, rank=rank, reduce_dtype=rd)
+out = []
+for step in range(2):
+    ids, mask, labels, pv = make_batch(dims, B, L, seed=20 + step, ragged=False)
+    sl = slice(rank * B // world, (rank + 1) * B // world)
+    ts.set_batch(ids[sl], mask[sl], pv[sl], labels[sl])
+    loss, norm = ts.step(1e-3)
+    out.append((loss.item(), norm.item()))
+sd = ts.store.master_state_dict(ts.comm)
+live = {k: v.cpu() for k, v in w.state_dict().items()}
+if rank == 0:
+    torch.save({"log": out, "master": {k: v.cpu() for k, v in sd.items()}, "live": live}, os.environ["BL_OUT"])
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("reduce", ["fp32", "bf16"])
+def test_two_rank_sharded_step_matches_single_process(dev, tmp_path, reduce):
+    from bridgelang_amd.training.step import TrainStep
+    from bridgelang_amd.weights import allocate, tiny_dims
+    dims = tiny_dims()
+    w = allocate(dims, dev).fill_synthetic(seed=3)
+    B, L = 4, 20
+    ts = TrainStep(w, "vla-train", B, L, max_grad_norm=1.0, weight_decay=0.1)
+    log = []
+    for step in range(2):
+        ids, mask, labels, pv = make_batch(dims, B, L, seed=20 + step, ragged=False)
+        ts.set_batch(ids, mask, pv, labels)
+        loss, norm = ts.step(1e-3)
+        log.append((loss.item(), norm.item()))
+    ref = {k: v.cpu() for k, v in ts.store.master_state_dict().items()}
+    torch.cuda.synchronize()
+    script, out = tmp_path / "worker.py", tmp_path / "out.pt"
+    script.write_text(_WORKER)
+    env = dict(os.environ, BL_ROOT=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT="29551", WORLD_SIZE="2", BL_OUT=str(out),
+               BL_REDUCE=reduce)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    got = torch.load(out, weights_only=True)
+    print("single:", log, "sharded rank0:", got["log"])
+    tol = 3e-2 if reduce == "bf16" else 5e-3
+    for (l1, n1), (l2, n2) in zip(log, got["log"]):
+        assert abs(n1 - n2) <= tol * n1                       # global grad norm (all-reduced) = single-process norm
+    worst = 1.0
+    for k, v in ref.items():
+        upd_ref, upd = v - w0(k, dims, dev), got["master"][k] - w0(k, dims, dev)
+        c = torch.nn.functional.cosine_similarity(upd_ref.flatten().double(), upd.flatten().double(), dim=0).item()
+        worst = min(worst, c)
+        assert c > (0.90 if reduce == "bf16" else 0.98), (k, c)
+        assert torch.equal(got["live"][k].float(), got["master"][k].to(torch.bfloat16).float()), k
+    print("worst update cosine", worst)
+
+
+_W0 = {}
+
+
+def w0(name, dims, dev):
+    if not _W0:
+        from bridgelang_amd.weights import allocate
+        _W0.update({k: v.float().cpu() for k, v in allocate(dims, dev).fill_synthetic(seed=3).state_dict().items()})
+    return _W0[name]

@@ -9,11 +9,11 @@ from oracle import restate as R
 pytestmark = pytest.mark.gpu
 
 
-def make_batch(dims, B, L, seed=0):
+def make_batch(dims, B, L, seed=0, ragged=True):
     g = torch.Generator().manual_seed(seed)
     ids = torch.randint(3, 31000, (B, L), generator=g)
     ids[:, 0] = 1
-    lens = [L - 3 * i for i in range(B)]
+    lens = [L - (3 * i if ragged else 0) for i in range(B)]
     mask = torch.zeros(B, L, dtype=torch.bool)
     labels = torch.full((B, L), -100)
     for i, n in enumerate(lens):
