@@ -146,6 +146,7 @@ class ParamStore:
         self.blocks_per_bucket = 256
         self.partial = torch.zeros(self.blocks_per_bucket * max(len(lay.buckets), 1), dtype=torch.float32, device=dev)
         self.norm_coef = torch.zeros(2, dtype=torch.float32, device=dev)     # [total norm, clip coefficient]
+        self.step_count = 0
 
     # ---- views ----
     def grad_view(self, name_or_unit) -> torch.Tensor:
@@ -210,6 +211,7 @@ class TrainStep:
             raise ValueError("training sequences are limited to 320 positions (whole-sequence attention kernels)")
         self.max_grad_norm, self.weight_decay, self.betas, self.eps = max_grad_norm, weight_decay, betas, eps
         self.store = store if store is not None else ParamStore(weights, stage, world, rank)
+        assert self.store.stage == stage
         st = self.store
         self.comm = ShardComm(st.layout, group, reduce_dtype)
         self.world = st.layout.world
@@ -258,7 +260,6 @@ class TrainStep:
         self._frozen_dw = z(max(D, Pv), dtype=torch.float32)                  # sink for norm-weight grads of frozen norms
         # ---- transposed weights for dgrad ----
         self._wT: Dict[int, torch.Tensor] = {}
-        self.step_count = 0
         self.forward_ops = self._plan_forward()
         self._ready: List[Tuple[int, str]] = []      # (number of backward ops enqueued, bucket key complete at that point)
         self.backward_ops = self._plan_backward()
@@ -506,13 +507,13 @@ class TrainStep:
         """AdamW on this rank's slice of the fp32 masters (decay classes per fsdp.py:200-212), all-gather of the updated
         bf16 slices, re-pack into the forward / dgrad layouts."""
         st, lay = self.store, self.store.layout
-        self.step_count += 1
+        st.step_count += 1
         main = torch.cuda.current_stream()
         for i in comm_order(lay.buckets):
             b = lay.buckets[i]
             lo, hi = lay.shard_range(b)
             sl = slice(lay.local_offset(b), lay.local_offset(b) + hi - lo)
-            T.adamw(st.master[sl], st.m[sl], st.v[sl], st.grad[lo:hi], self.step_count, lr, betas=self.betas, eps=self.eps,
+            T.adamw(st.master[sl], st.m[sl], st.v[sl], st.grad[lo:hi], st.step_count, lr, betas=self.betas, eps=self.eps,
                     weight_decay=self.weight_decay if b.decay else 0.0, norm_coef=st.norm_coef, p_bf16=st.stage_bf16[lo:hi])
             if self.comm.active:                                   # gather bucket i while AdamW runs on bucket i+1
                 ev = torch.cuda.Event()
