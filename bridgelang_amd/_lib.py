@@ -78,6 +78,7 @@ SIGNATURES = {
     "bl_cross_entropy_f32": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
     "bl_cross_entropy_backward_f32": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
     "bl_rmsnorm_backward_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
+    "bl_layernorm_backward_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "bl_colsum_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
     "bl_swiglu_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "bl_swiglu_backward_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
@@ -89,6 +90,10 @@ SIGNATURES = {
     "bl_clip_coef_f32": (C.c_int, [_vp, _i32, _f32, _vp, _vp]),
     "bl_adamw_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "bl_rope_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "bl_scale_residual_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
+    "bl_layerscale_backward_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "bl_memset_zero": (C.c_int, [_vp, _i64, _vp]),
+    "bl_copy_bytes": (C.c_int, [_vp, _vp, _i64, _vp]),
     "bl_map_rows_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "bl_embed_backward_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "bl_im2col_patch14_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _vp]),

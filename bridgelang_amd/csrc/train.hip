@@ -66,90 +66,123 @@ __global__ __launch_bounds__(256) void ce_backward_kernel(const float* logits, l
   }
 }
 
-// ---- RMSNorm backward (+ residual-stream gradient add), one wave per row ----
-//   g = w ⊙ dy;  x̂ = x·rstd;  dx = rstd·(g − x̂·mean(g ⊙ x̂)) [+ dres];  dw partial[block][j] = Σ_rows dy_j · bf16(x̂_j)
-template <int NCH>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const uint16_t* x, long ldx, const uint16_t* w,
-                                                          const uint16_t* dy, long lddy, const uint16_t* dres,
-                                                          long lddres, uint16_t* dx, long lddx, float* dw_partial,
-                                                          int rows, int dim, float eps, int rows_per_block) {
+// ---- RMSNorm / LayerNorm backward (+ residual-stream gradient add), one wave per row ----
+//   RMS: g = w ⊙ dy;  x̂ = x·rstd;        dx = rstd·(g − x̂·mean(g ⊙ x̂)) [+ dres];          dw = Σ_rows dy ⊙ bf16(x̂)
+//   LN : g = w ⊙ dy;  x̂ = (x − μ)·rstd;  dx = rstd·(g − mean(g) − x̂·mean(g ⊙ x̂)) [+ dres]; dw = Σ dy ⊙ x̂;  db = Σ dy
+// Per-block partials of dw (and db, stored behind the dw partials) are summed by reduce_partials_kernel.
+template <int NCH, bool LN>
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const uint16_t* x, long ldx, const uint16_t* w,
+                                                       const uint16_t* dy, long lddy, const uint16_t* dres,
+                                                       long lddres, uint16_t* dx, long lddx, float* dw_partial,
+                                                       int rows, int dim, float eps, int rows_per_block) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = dim >> 3;
-  float dwacc[NCH][8];
+  const float inv_dim = 1.0f / (float)dim;
+  float dwacc[NCH][8], dbacc[LN ? NCH : 1][8];
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dwacc[c][i] = 0.f;
+    for (int i = 0; i < 8; ++i) { dwacc[c][i] = 0.f; if (LN) dbacc[c][i] = 0.f; }
   const int r0 = blockIdx.x * rows_per_block;
   for (int rr = wave; rr < rows_per_block; rr += 4) {
     const int row = r0 + rr;
     if (row >= rows) break;
-    float xv[NCH][8], gv[NCH][8], dyv[NCH][8];
-    float ss = 0.f;
+    float xv[NCH][8], dyv[NCH][8];
+    float sx = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = c * 64 + lane;
-      const bool in = ch < nchunk;
-      u32x4_t qx = {0u, 0u, 0u, 0u}, qd = qx, qw = qx;
-      if (in) {
+      u32x4_t qx = {0u, 0u, 0u, 0u}, qd = qx;
+      if (ch < nchunk) {
         qx = *(const u32x4_t*)(x + (long)row * ldx + ch * 8);
         qd = *(const u32x4_t*)(dy + (long)row * lddy + ch * 8);
-        qw = *(const u32x4_t*)(w + ch * 8);
       }
-      float wv[8];
-      unpack8(qx, xv[c]); unpack8(qd, dyv[c]); unpack8(qw, wv);
+      unpack8(qx, xv[c]); unpack8(qd, dyv[c]);
+      if (LN) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { gv[c][i] = wv[i] * dyv[c][i]; ss += xv[c][i] * xv[c][i]; }
+        for (int i = 0; i < 8; ++i) sx += xv[c][i];
+      }
+    }
+    float mu = 0.f;
+    if (LN) mu = wave_sum(sx) * inv_dim;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const bool in = c * 64 + lane < nchunk;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (LN) xv[c][i] = in ? xv[c][i] - mu : 0.f;
+        ss += xv[c][i] * xv[c][i];
+      }
     }
     ss = wave_sum(ss);
-    const float rstd = 1.0f / sqrtf(ss * (1.0f / (float)dim) + eps);
-    float dot = 0.f;
+    const float rstd = 1.0f / sqrtf(ss * inv_dim + eps);
+    float dot = 0.f, gsum = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = c * 64 + lane;
+      float wv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (ch < nchunk) unpack8(*(const u32x4_t*)(w + ch * 8), wv);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) dot += gv[c][i] * xv[c][i] * rstd;
-    dot = wave_sum(dot) * (1.0f / (float)dim);
+      for (int i = 0; i < 8; ++i) {
+        const float g = wv[i] * dyv[c][i];
+        dot += g * xv[c][i] * rstd;
+        if (LN) gsum += g;
+      }
+    }
+    dot = wave_sum(dot) * inv_dim;
+    if (LN) gsum = wave_sum(gsum) * inv_dim;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = c * 64 + lane;
       if (ch >= nchunk) continue;
-      float o[8], dr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float o[8], dr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wv[8];
+      unpack8(*(const u32x4_t*)(w + ch * 8), wv);
       if (dres) unpack8(*(const u32x4_t*)(dres + (long)row * lddres + ch * 8), dr);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float xh = xv[c][i] * rstd;
-        o[i] = rstd * (gv[c][i] - xh * dot) + dr[i];
-        dwacc[c][i] += dyv[c][i] * rbf(xh);
+        o[i] = rstd * (wv[i] * dyv[c][i] - gsum - xh * dot) + dr[i];
+        dwacc[c][i] += dyv[c][i] * (LN ? xh : rbf(xh));
+        if (LN) dbacc[c][i] += dyv[c][i];
       }
       *(u32x4_t*)(dx + (long)row * lddx + ch * 8) = pack8(o);
     }
   }
-  // per-block dw partial: the 4 waves of the block own disjoint rows → sum them through LDS, lane-major
+  // per-block partials: the 4 waves of the block own disjoint rows → sum them through LDS, lane-major
   __shared__ float sh[4][64 * 8];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
+  for (int pass = 0; pass < (LN ? 2 : 1); ++pass) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sh[wave][lane * 8 + i] = dwacc[c][i];
-    __syncthreads();
-    if (wave == 0) {
-      const int ch = c * 64 + lane;
-      if (ch < nchunk) {
+    for (int c = 0; c < NCH; ++c) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-          dw_partial[(long)blockIdx.x * dim + ch * 8 + i] = sh[0][lane * 8 + i] + sh[1][lane * 8 + i] + sh[2][lane * 8 + i] + sh[3][lane * 8 + i];
+      for (int i = 0; i < 8; ++i) sh[wave][lane * 8 + i] = (LN && pass) ? dbacc[c][i] : dwacc[c][i];
+      __syncthreads();
+      if (wave == 0) {
+        const int ch = c * 64 + lane;
+        if (ch < nchunk) {
+          float* dst = dw_partial + ((long)pass * gridDim.x + blockIdx.x) * dim + ch * 8;
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            dst[i] = sh[0][lane * 8 + i] + sh[1][lane * 8 + i] + sh[2][lane * 8 + i] + sh[3][lane * 8 + i];
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 
-// out[j] = Σ_b partial[b][j]   (fixed order → deterministic)
-__global__ void reduce_partials_kernel(const float* partial, int nblocks, int dim, float* out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= dim) return;
+// out[j] = Σ_b partial[b][j]   (fixed order → deterministic). Block = 64 columns × 4 row groups.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* partial, int nblocks, int dim, float* out) {
+  __shared__ float sh[4][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * dim + j];
-  out[j] = s;
+  if (j < dim)
+    for (int b = rg; b < nblocks; b += 4) s += partial[(long)b * dim + j];
+  sh[rg][c] = s;
+  __syncthreads();
+  if (rg == 0 && j < dim) out[j] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
 }
 
 // column sums of a bf16 matrix [rows, cols] → per-block partials (bias gradients)
@@ -249,6 +282,45 @@ __global__ void rope_bwd_kernel(uint16_t* dqkv, int B, int S, int H, int hd, con
     *(u32x4_t*)p = pack8(o1);
     *(u32x4_t*)(p + half) = pack8(o2);
   }
+}
+
+// ---- LayerScale residual (timm LayerScale patched to `scale_factor`, modeling_prismatic.py:52-59) ----
+// forward:  y = bf16(bf16(u ⊙ ls) + res)           (u = the branch output, kept for the backward)
+// backward: du = dy ⊙ ls;  dls partial[block][j] = Σ_rows dy ⊙ u
+__global__ void scale_residual_kernel(const uint16_t* u, long ldu, const uint16_t* ls, const uint16_t* res, long ldr,
+                                      uint16_t* y, long ldy, long rows, int cols) {
+  const int cpr = cols >> 3;
+  const long total = rows * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cpr;
+    const int ch = (int)(i - r * cpr);
+    float a[8], s[8], b[8], o[8];
+    unpack8(*(const u32x4_t*)(u + r * ldu + ch * 8), a);
+    unpack8(*(const u32x4_t*)(ls + ch * 8), s);
+    unpack8(*(const u32x4_t*)(res + r * ldr + ch * 8), b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = rbf(a[e] * s[e]) + b[e];
+    *(u32x4_t*)(y + r * ldy + ch * 8) = pack8(o);
+  }
+}
+__global__ __launch_bounds__(256) void layerscale_bwd_kernel(const uint16_t* dy, long lddy, const uint16_t* u, long ldu,
+                                                             const uint16_t* ls, uint16_t* du, long lddu, int rows,
+                                                             int cols, int rows_per_block, float* partial) {
+  const int col8 = (blockIdx.y * 256 + threadIdx.x) * 8;
+  if (col8 >= cols) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s[8];
+  unpack8(*(const u32x4_t*)(ls + col8), s);
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (int r = r0; r < r1; ++r) {
+    float g[8], a[8], o[8];
+    unpack8(*(const u32x4_t*)(dy + (long)r * lddy + col8), g);
+    unpack8(*(const u32x4_t*)(u + (long)r * ldu + col8), a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { acc[e] += g[e] * a[e]; o[e] = g[e] * s[e]; }
+    *(u32x4_t*)(du + (long)r * lddu + col8) = pack8(o);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) partial[(long)blockIdx.x * cols + col8 + e] = acc[e];
 }
 
 // ---- row gather / scatter: out row r ↔ src row (r / group) * stride + offset + r % group (the projector's 256 patch rows
@@ -376,25 +448,84 @@ extern "C" int bl_cross_entropy_backward_f32(const float* logits, int64_t ld, in
   return BL_OK;
 }
 
-extern "C" int bl_rmsnorm_backward_bf16(const bl_bf16* x, int64_t ldx, const bl_bf16* w, const bl_bf16* dy, int64_t lddy,
-                                        const bl_bf16* dres, int64_t lddres, bl_bf16* dx, int64_t lddx, float* dw,
-                                        float* partial_ws, int64_t partial_ws_floats, int32_t rows, int32_t dim,
-                                        float eps, void* stream) {
-  if (!x || !w || !dy || !dx || !dw || !partial_ws) return BL_E_ARG;
+template <bool LN>
+static int norm_backward(const bl_bf16* x, int64_t ldx, const bl_bf16* w, const bl_bf16* dy, int64_t lddy, const bl_bf16* dres,
+                         int64_t lddres, bl_bf16* dx, int64_t lddx, float* dw, float* db, float* partial_ws,
+                         int64_t partial_ws_floats, int32_t rows, int32_t dim, float eps, void* stream) {
+  if (!x || !w || !dy || !dx || !dw || !partial_ws || (LN && !db)) return BL_E_ARG;
   if (rows <= 0 || dim <= 0 || (dim % 8) || dim > 64 * 8 * 10) return BL_E_SHAPE;
   if ((ldx % 8) || (lddy % 8) || (lddx % 8) || (dres && (lddres % 8))) return BL_E_ALIGN;
-  const int rpb = 64, nblk = (rows + rpb - 1) / rpb;
-  if (partial_ws_floats < (int64_t)nblk * dim) return BL_E_SHAPE;
+  // rows per block: as few as the partial workspace allows (>= 16: four rows per wave), so the grid covers the chip
+  int rpb = 16;
+  while ((int64_t)((rows + rpb - 1) / rpb) * dim * (LN ? 2 : 1) > partial_ws_floats) {
+    rpb *= 2;
+    if (rpb > 4096) return BL_E_SHAPE;
+  }
+  const int nblk = (rows + rpb - 1) / rpb;
   const int nch = (dim / 8 + 63) / 64;
   hipStream_t s = (hipStream_t)stream;
-#define BL_CASE(N) case N: hipLaunchKernelGGL((rmsnorm_bwd_kernel<N>), dim3(nblk), dim3(256), 0, s, x, (long)ldx, w, dy, \
+#define BL_CASE(N) case N: hipLaunchKernelGGL((norm_bwd_kernel<N, LN>), dim3(nblk), dim3(256), 0, s, x, (long)ldx, w, dy, \
     (long)lddy, dres, (long)lddres, dx, (long)lddx, partial_ws, rows, dim, eps, rpb); break;
   switch (nch) { BL_CASE(1) BL_CASE(2) BL_CASE(3) BL_CASE(4) BL_CASE(5) BL_CASE(6) BL_CASE(7) BL_CASE(8) BL_CASE(9) BL_CASE(10)
     default: return BL_E_SHAPE; }
 #undef BL_CASE
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((dim + 255) / 256), dim3(256), 0, s, partial_ws, nblk, dim, dw);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((dim + 63) / 64), dim3(256), 0, s, partial_ws, nblk, dim, dw);
+  if (LN)
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((dim + 63) / 64), dim3(256), 0, s, partial_ws + (long)nblk * dim, nblk, dim, db);
   BL_CHECK_LAUNCH();
   return BL_OK;
+}
+
+extern "C" int bl_rmsnorm_backward_bf16(const bl_bf16* x, int64_t ldx, const bl_bf16* w, const bl_bf16* dy, int64_t lddy,
+                                        const bl_bf16* dres, int64_t lddres, bl_bf16* dx, int64_t lddx, float* dw,
+                                        float* partial_ws, int64_t partial_ws_floats, int32_t rows, int32_t dim,
+                                        float eps, void* stream) {
+  return norm_backward<false>(x, ldx, w, dy, lddy, dres, lddres, dx, lddx, dw, nullptr, partial_ws, partial_ws_floats, rows,
+                              dim, eps, stream);
+}
+
+extern "C" int bl_layernorm_backward_bf16(const bl_bf16* x, int64_t ldx, const bl_bf16* w, const bl_bf16* dy, int64_t lddy,
+                                          const bl_bf16* dres, int64_t lddres, bl_bf16* dx, int64_t lddx, float* dw,
+                                          float* db, float* partial_ws, int64_t partial_ws_floats, int32_t rows,
+                                          int32_t dim, float eps, void* stream) {
+  return norm_backward<true>(x, ldx, w, dy, lddy, dres, lddres, dx, lddx, dw, db, partial_ws, partial_ws_floats, rows, dim,
+                             eps, stream);
+}
+
+extern "C" int bl_scale_residual_bf16(const bl_bf16* u, int64_t ldu, const bl_bf16* scale, const bl_bf16* res, int64_t ldres,
+                                      bl_bf16* y, int64_t ldy, int64_t rows, int32_t cols, void* stream) {
+  if (!u || !scale || !res || !y) return BL_E_ARG;
+  if (rows <= 0 || cols <= 0 || (cols % 8) || (ldu % 8) || (ldres % 8) || (ldy % 8)) return BL_E_SHAPE;
+  hipLaunchKernelGGL(scale_residual_kernel, dim3(grid_for(rows * (cols / 8), 256)), dim3(256), 0, (hipStream_t)stream, u,
+                     (long)ldu, scale, res, (long)ldres, y, (long)ldy, (long)rows, cols);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_layerscale_backward_bf16(const bl_bf16* dy, int64_t lddy, const bl_bf16* u, int64_t ldu, const bl_bf16* scale,
+                                           bl_bf16* du, int64_t lddu, float* dscale, float* partial_ws,
+                                           int64_t partial_ws_floats, int32_t rows, int32_t cols, void* stream) {
+  if (!dy || !u || !scale || !du || !dscale || !partial_ws) return BL_E_ARG;
+  if (rows <= 0 || cols <= 0 || (cols % 8) || (lddy % 8) || (ldu % 8) || (lddu % 8)) return BL_E_SHAPE;
+  const int rpb = 64, nblk = (rows + rpb - 1) / rpb;
+  if (partial_ws_floats < (int64_t)nblk * cols) return BL_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(layerscale_bwd_kernel, dim3(nblk, (cols / 8 + 255) / 256), dim3(256), 0, s, dy, (long)lddy, u, (long)ldu,
+                     scale, du, (long)lddu, rows, cols, rpb, partial_ws);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial_ws, nblk, cols, dscale);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+// plain device memset / copy as replayable ops of the step plans (gradient buffers that are accumulated into, small
+// gradient slots that are filled from a shared scratch)
+extern "C" int bl_memset_zero(void* dst, int64_t bytes, void* stream) {
+  if (!dst || bytes <= 0) return BL_E_ARG;
+  return hipMemsetAsync(dst, 0, (size_t)bytes, (hipStream_t)stream) == hipSuccess ? BL_OK : BL_E_LAUNCH;
+}
+extern "C" int bl_copy_bytes(void* dst, const void* src, int64_t bytes, void* stream) {
+  if (!dst || !src || bytes <= 0) return BL_E_ARG;
+  return hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? BL_OK : BL_E_LAUNCH;
 }
 
 extern "C" int bl_colsum_bf16(const bl_bf16* a, int64_t lda, int32_t rows, int32_t cols, float* out, float* partial_ws,
@@ -406,7 +537,7 @@ extern "C" int bl_colsum_bf16(const bl_bf16* a, int64_t lda, int32_t rows, int32
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, (cols / 8 + 255) / 256), dim3(256), 0, s, a, (long)lda, rows, cols,
                      rpb, partial_ws);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, partial_ws, nblk, cols, out);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial_ws, nblk, cols, out);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

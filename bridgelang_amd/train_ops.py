@@ -151,3 +151,38 @@ def pack(w: torch.Tensor, out: torch.Tensor, run: bool = True) -> Op:
     assert out.numel() == N * K and N % 16 == 0 and K % 32 == 0
     return _op("bl_pack_weight_bf16", (_bf16(w, "w").data_ptr(), _rows(w, "w"), N, K, _bf16(out, "out").data_ptr()), (w, out), run,
                nbytes=4.0 * N * K)
+
+
+def layernorm_backward(x, w, dy, dx, dw, db, ws, eps: float, dres: Optional[torch.Tensor] = None, run: bool = True) -> Op:
+    rows, dim = x.shape
+    return _op("bl_layernorm_backward_bf16",
+               (_bf16(x, "x").data_ptr(), _rows(x, "x"), _bf16(w, "w").data_ptr(), _bf16(dy, "dy").data_ptr(), _rows(dy, "dy"),
+                dres.data_ptr() if dres is not None else None, _rows(dres, "dres") if dres is not None else 0,
+                _bf16(dx, "dx").data_ptr(), _rows(dx, "dx"), _f32(dw, "dw").data_ptr(), _f32(db, "db").data_ptr(),
+                _f32(ws, "ws").data_ptr(), ws.numel(), rows, dim, float(eps)), (x, w, dy, dx, dw, db, ws, dres), run,
+               nbytes=2.0 * rows * dim * (4 if dres is not None else 3))
+
+
+def scale_residual(u, scale, res, y, run: bool = True) -> Op:
+    rows, cols = u.shape
+    return _op("bl_scale_residual_bf16", (_bf16(u, "u").data_ptr(), _rows(u, "u"), _bf16(scale, "scale").data_ptr(),
+                                          _bf16(res, "res").data_ptr(), _rows(res, "res"), _bf16(y, "y").data_ptr(), _rows(y, "y"),
+                                          rows, cols), (u, scale, res, y), run, nbytes=6.0 * rows * cols)
+
+
+def layerscale_backward(dy, u, scale, du, dscale, ws, run: bool = True) -> Op:
+    rows, cols = dy.shape
+    return _op("bl_layerscale_backward_bf16",
+               (_bf16(dy, "dy").data_ptr(), _rows(dy, "dy"), _bf16(u, "u").data_ptr(), _rows(u, "u"), _bf16(scale, "scale").data_ptr(),
+                _bf16(du, "du").data_ptr(), _rows(du, "du"), _f32(dscale, "dscale").data_ptr(), _f32(ws, "ws").data_ptr(), ws.numel(),
+                rows, cols), (dy, u, scale, du, dscale, ws), run, nbytes=6.0 * rows * cols)
+
+
+def fill_zero(t: torch.Tensor, run: bool = True) -> Op:
+    assert t.is_contiguous()
+    return _op("bl_memset_zero", (t.data_ptr(), t.numel() * t.element_size()), (t,), run, nbytes=float(t.numel() * t.element_size()))
+
+
+def copy_f32(src: torch.Tensor, dst: torch.Tensor, run: bool = True) -> Op:
+    assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel() and src.dtype == dst.dtype
+    return _op("bl_copy_bytes", (dst.data_ptr(), src.data_ptr(), src.numel() * src.element_size()), (src, dst), run)

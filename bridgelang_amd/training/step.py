@@ -201,9 +201,7 @@ class TrainStep:
     def __init__(self, weights: VLAWeights, stage: str, batch: int, prompt_len: int, *, max_grad_norm: float = 1.0,
                  weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8, store: Optional[ParamStore] = None,
                  world: int = 1, rank: int = 0, group=None, reduce_dtype: torch.dtype = torch.float32):
-        vision, _, _ = STAGES[stage]
-        if vision:
-            raise NotImplementedError("vision-backbone backward (stages *-full-train / sandwich) is not built yet")
+        self.train_vision = STAGES[stage][0]
         self.w, self.dims, self.stage = weights, weights.dims, stage
         d = self.dims
         self.B, self.L, self.S = batch, prompt_len, prompt_len + d.n_patches
@@ -255,11 +253,19 @@ class TrainStep:
         self.dp3, self.dp2, self.dz2, self.dp1, self.dz1 = z(B * 256, D), z(B * 256, D), z(B * 256, D), z(B * 256, Pv), z(B * 256, Pv)
         nmax = max(V, 3 * D, 2 * I, Pv)
         self.tA, self.tB, self.tBp = z(nmax * self.Tp), z(nmax * self.Tp), z(nmax * self.Tp)
-        self.norm_ws = z(((Tn + 63) // 64) * D, dtype=torch.float32)
-        self.col_ws = z(((Tn + 255) // 256) * max(Pv, D), dtype=torch.float32)
+        towers = (weights.dino, weights.siglip) if self.train_vision else ()
+        mv = max((B * tw.dims.tokens for tw in towers), default=0)
+        dv_ = max((tw.dims.dim for tw in towers), default=0)
+        self.norm_ws = z(max(((Tn + 15) // 16) * D, 2 * ((mv + 15) // 16) * dv_), dtype=torch.float32)
+        self.col_ws = z(max(((Tn + 255) // 256) * max(Pv, D), 256 * dv_, ((mv + 63) // 64) * dv_ * 4), dtype=torch.float32)
         self._frozen_dw = z(max(D, Pv), dtype=torch.float32)                  # sink for norm-weight grads of frozen norms
+        self.dfeats = z(B * 256, d.vision_dim) if self.train_vision else None
+        self.vis = [self._alloc_tower(tw) for tw in towers]
         # ---- transposed weights for dgrad ----
         self._wT: Dict[int, torch.Tensor] = {}
+        self.vision_forward_ops: List[Op] = []
+        for tw, sv, col in zip(towers, self.vis, (0, d.dino.dim)):
+            self.vision_forward_ops += self._plan_tower_forward(tw, col, sv)
         self.forward_ops = self._plan_forward()
         self._ready: List[Tuple[int, str]] = []      # (number of backward ops enqueued, bucket key complete at that point)
         self.backward_ops = self._plan_backward()
@@ -287,10 +293,12 @@ class TrainStep:
         Tn, N = dy.shape
         K = x.shape[1]
         assert (N, K) == (u.group.n, u.group.k), (dy.shape, x.shape, u.group.n, u.group.k)
-        tA = self.tA[:N * self.Tp].view(N, self.Tp)
-        tB = self.tB[:K * self.Tp].view(K, self.Tp)
-        tBp = self.tBp[:K * self.Tp].view(K // 16, self.Tp // 32, 64, 8)
-        return [T.transpose_pad(dy, tA, self.Tp, run=False), T.transpose_pad(x, tB, self.Tp, run=False),
+        Tp = (Tn + 63) // 64 * 64
+        assert max(N, K) * Tp <= self.tA.numel()
+        tA = self.tA[:N * Tp].view(N, Tp)
+        tB = self.tB[:K * Tp].view(K, Tp)
+        tBp = self.tBp[:K * Tp].view(K // 16, Tp // 32, 64, 8)
+        return [T.transpose_pad(dy, tA, Tp, run=False), T.transpose_pad(x, tB, Tp, run=False),
                 T.pack(tB, tBp, run=False), ops.gemm(tA, tBp, self.store.grad_view(u), EPI_F32, algo_nk=(K, Tn), run=False)]
 
     def _gvec(self, name: str, n: int) -> torch.Tensor:
@@ -366,6 +374,7 @@ class TrainStep:
             return plan
         # dx = gradient of inputs_embeds [B, S, D]
         if st.trainable(f"{lm}.embed_tokens.weight"):
+            plan.append(T.fill_zero(st.grad_view(f"{lm}.embed_tokens.weight"), run=False))     # accumulated with atomics
             plan.append(T.embed_backward(self.input_ids, dx.view(B, S, D), st.grad_view(f"{lm}.embed_tokens.weight").view(d.vocab, D),
                                          d.n_patches, run=False))
         if st.trainable("projector.fc3.weight"):
@@ -381,6 +390,121 @@ class TrainStep:
             plan.append(T.colsum(self.dz1, st.grad_view("projector.fc1.bias"), self.col_ws, run=False))
             plan += self._wgrad(self.dz1, self.feats, w.fc1_w)
             self._ready.append((len(plan), "projector"))
+            if self.train_vision:
+                plan.append(self._dgrad(self.dz1, w.fc1_w, self.dfeats))
+                for tw, sv, col in zip((w.dino, w.siglip), self.vis, (0, d.dino.dim)):
+                    plan += self._plan_tower_backward(tw, col, sv, len(plan))
+        return plan
+
+    # ---- vision towers in training form (timm VisionTransformer blocks) ---------------------------
+    def _alloc_tower(self, tw) -> dict:
+        t, B = tw.dims, self.B
+        M, Dm, Hp, n = B * t.tokens, t.dim, t.mlp_pad, t.n_run
+        z = lambda *shape, dtype=torch.bfloat16: torch.zeros(*shape, dtype=dtype, device=self.device)
+        pad = (t.tokens + 31) // 32 * 32
+        ls = t.layerscale
+        return dict(
+            x=[z(M, Dm) for _ in range(n + 1)], h1=[z(M, Dm) for _ in range(n)], qkv=[z(M, 3 * Dm) for _ in range(n)],
+            ao=[z(M, Dm) for _ in range(n)], lse=[z(B * t.heads * pad, dtype=torch.float32) for _ in range(n)],
+            xm=[z(M, Dm) for _ in range(n)], h2=[z(M, Dm) for _ in range(n)], zz=[z(M, Hp) for _ in range(n)],
+            f=[z(M, Hp) for _ in range(n)], u1=[z(M, Dm) if ls else None for _ in range(n)],
+            u2=[z(M, Dm) if ls else None for _ in range(n)], delta=z(B * t.heads * pad, dtype=torch.float32),
+            dxa=z(M, Dm), dxb=z(M, Dm), dh=z(M, Dm), du=z(M, Dm), dao=z(M, Dm), dqkv=z(M, 3 * Dm), df=z(M, Hp), dz=z(M, Hp),
+            dpe=z(B * 256, Dm), tok=z(max(t.n_prefix, 1) * Dm, dtype=torch.float32))
+
+    def _plan_tower_forward(self, tw, feat_col: int, sv: dict) -> List[Op]:
+        t, B, eps = tw.dims, self.B, self.dims.ln_eps
+        Tk, Dm, hd = t.tokens, t.dim, t.head_dim
+        col = self._vis.vbuf[1 if feat_col else 0]["col"]          # one im2col buffer per tower (kept for the patch wgrad)
+        g = lambda *a, **k: ops.gemm(*a, run=False, **k)
+        x0 = sv["x"][0]
+        plan = [ops.im2col_patch14(self.pixel_values, t.chan0, col, run=False)]
+        if tw.prefix is not None:
+            plan.append(ops.write_prefix_tokens(tw.prefix, x0, B, Tk, run=False))
+        plan.append(g(col, tw.patch_w, x0, ops.EPI_BIAS_RES, bias=tw.patch_b, res=tw.pos, res_row_mod=256,
+                      out_map=(256, Tk, t.n_prefix)))
+        st = (Tk * 3 * Dm, hd, 3 * Dm)
+        for i, b in enumerate(tw.blocks):
+            x, xm, qkv = sv["x"][i], sv["xm"][i], sv["qkv"][i]
+            plan += [ops.layernorm(x, b.norm1_w, b.norm1_b, sv["h1"][i], eps, run=False),
+                     g(sv["h1"][i], b.qkv_w, qkv, EPI_BIAS, bias=b.qkv_b),
+                     T.attention_lse(qkv, qkv[:, Dm:], qkv[:, 2 * Dm:], sv["ao"][i], sv["lse"][i], B=B, H=t.heads, Sq=Tk,
+                                     Skv=Tk, head_dim=hd, q_strides=st, k_strides=st, v_strides=st,
+                                     o_strides=(Tk * Dm, hd, Dm), causal=False, run=False)]
+            if b.ls1 is not None:
+                plan += [g(sv["ao"][i], b.proj_w, sv["u1"][i], EPI_BIAS, bias=b.proj_b),
+                         T.scale_residual(sv["u1"][i], b.ls1, x, xm, run=False)]
+            else:
+                plan.append(g(sv["ao"][i], b.proj_w, xm, ops.EPI_BIAS_RES, bias=b.proj_b, res=x))
+            plan += [ops.layernorm(xm, b.norm2_w, b.norm2_b, sv["h2"][i], eps, run=False),
+                     g(sv["h2"][i], b.fc1_w, sv["zz"][i], EPI_BIAS, bias=b.fc1_b),
+                     T.gelu(sv["zz"][i], sv["f"][i], run=False)]
+            if b.ls2 is not None:
+                plan += [g(sv["f"][i], b.fc2_w, sv["u2"][i], EPI_BIAS, bias=b.fc2_b),
+                         T.scale_residual(sv["u2"][i], b.ls2, xm, sv["x"][i + 1], run=False)]
+            else:
+                plan.append(g(sv["f"][i], b.fc2_w, sv["x"][i + 1], ops.EPI_BIAS_RES, bias=b.fc2_b, res=xm))
+        # tap: patch rows of the last block output → this tower's channels of the fused feature map
+        plan.append(T.map_rows(sv["x"][-1], self.feats[:, feat_col:feat_col + Dm], rows=B * 256, group=256, stride=Tk,
+                               offset=t.n_prefix, scatter=False, run=False))
+        return plan
+
+    def _plan_tower_backward(self, tw, feat_col: int, sv: dict, base: int) -> List[Op]:
+        """`base` = ops already in the backward plan (bucket-ready markers are absolute positions)."""
+        t, B, eps, st = tw.dims, self.B, self.dims.ln_eps, self.store
+        Tk, Dm, hd, M = t.tokens, t.dim, t.head_dim, B * t.tokens
+        p = t.prefix
+        tower_key = p.split(".")[1]
+        gv = lambda name: st.grad_view(name)
+        dx, dx2 = sv["dxa"], sv["dxb"]
+        plan: List[Op] = [T.fill_zero(dx, run=False),
+                          T.map_rows(self.dfeats[:, feat_col:feat_col + Dm], dx, rows=B * 256, group=256, stride=Tk,
+                                     offset=t.n_prefix, scatter=True, run=False)]
+        strides = (Tk * 3 * Dm, hd, 3 * Dm)
+        for i in range(t.n_run - 1, -1, -1):
+            b, bn = tw.blocks[i], f"{p}.blocks.{i}"
+            dbr = dx
+            if b.ls2 is not None:
+                plan.append(T.layerscale_backward(dx, sv["u2"][i], b.ls2, sv["du"], gv(f"{bn}.ls2.scale_factor"), self.col_ws, run=False))
+                dbr = sv["du"]
+            plan.append(T.colsum(dbr, gv(f"{bn}.mlp.fc2.bias"), self.col_ws, run=False))
+            plan += self._wgrad(dbr, sv["f"][i], b.fc2_w)
+            plan.append(self._dgrad(dbr, b.fc2_w, sv["df"]))
+            plan.append(T.gelu_backward(sv["zz"][i], sv["df"], sv["dz"], run=False))
+            plan.append(T.colsum(sv["dz"][:, :t.mlp], gv(f"{bn}.mlp.fc1.bias"), self.col_ws, run=False))
+            plan += self._wgrad(sv["dz"], sv["h2"][i], b.fc1_w)
+            plan.append(self._dgrad(sv["dz"], b.fc1_w, sv["dh"]))
+            plan.append(T.layernorm_backward(sv["xm"][i], b.norm2_w, sv["dh"], dx2, gv(f"{bn}.norm2.weight"), gv(f"{bn}.norm2.bias"),
+                                             self.norm_ws, eps, dres=dx, run=False))
+            dbr = dx2
+            if b.ls1 is not None:
+                plan.append(T.layerscale_backward(dx2, sv["u1"][i], b.ls1, sv["du"], gv(f"{bn}.ls1.scale_factor"), self.col_ws, run=False))
+                dbr = sv["du"]
+            plan.append(T.colsum(dbr, gv(f"{bn}.attn.proj.bias"), self.col_ws, run=False))
+            plan += self._wgrad(dbr, sv["ao"][i], b.proj_w)
+            plan.append(self._dgrad(dbr, b.proj_w, sv["dao"]))
+            qkv, dq = sv["qkv"][i], sv["dqkv"]
+            plan.append(T.attention_backward(qkv, qkv[:, Dm:], qkv[:, 2 * Dm:], sv["ao"][i], sv["dao"], sv["lse"][i], sv["delta"],
+                                             dq, dq[:, Dm:], dq[:, 2 * Dm:], B=B, H=t.heads, Sq=Tk, Skv=Tk, head_dim=hd,
+                                             q_strides=strides, k_strides=strides, v_strides=strides,
+                                             o_strides=(Tk * Dm, hd, Dm), causal=False, run=False))
+            plan.append(T.colsum(dq, gv(f"{bn}.attn.qkv.bias"), self.col_ws, run=False))
+            plan += self._wgrad(dq, sv["h1"][i], b.qkv_w)
+            self._ready.append((base + len(plan), f"vision.{tower_key}.block{i:02d}"))
+            plan.append(self._dgrad(dq, b.qkv_w, sv["dh"]))
+            plan.append(T.layernorm_backward(sv["x"][i], b.norm1_w, sv["dh"], dx, gv(f"{bn}.norm1.weight"), gv(f"{bn}.norm1.bias"),
+                                             self.norm_ws, eps, dres=dx2, run=False))
+        # stem: dx = gradient of [prefix tokens | patch embeddings + pos]
+        dxv = dx.view(B, Tk * Dm)
+        plan.append(T.colsum(dxv[:, t.n_prefix * Dm:], gv(f"{p}.pos_embed"), self.col_ws, run=False))
+        if t.n_prefix:
+            plan.append(T.colsum(dxv[:, :t.n_prefix * Dm], sv["tok"], self.col_ws, run=False))
+            plan.append(T.copy_f32(sv["tok"][:Dm], gv(f"{p}.cls_token"), run=False))
+            plan.append(T.copy_f32(sv["tok"][Dm:t.n_prefix * Dm], gv(f"{p}.reg_token"), run=False))
+        plan.append(T.map_rows(dx, sv["dpe"], rows=B * 256, group=256, stride=Tk, offset=t.n_prefix, scatter=False, run=False))
+        plan.append(T.colsum(sv["dpe"], gv(f"{p}.patch_embed.proj.bias"), self.col_ws, run=False))
+        plan += self._wgrad(sv["dpe"], self._vis.vbuf[1 if feat_col else 0]["col"], tw.patch_w)
+        self._ready.append((base + len(plan), f"vision.{tower_key}.stem"))
         return plan
 
     def _lowest_needed_layer(self) -> int:
@@ -454,7 +578,10 @@ class TrainStep:
 
     def forward(self, graph: bool = False) -> torch.Tensor:
         """Vision towers (frozen) → projector → decoder → loss. Returns the device scalar loss."""
-        self._vis.run_vision()
+        if self.train_vision:
+            self._replay("vfwd", self.vision_forward_ops, graph)
+        else:
+            self._vis.run_vision()
         self._replay("fwd", self.forward_ops, graph)
         return self.mean_cnt[0]
 
@@ -462,9 +589,6 @@ class TrainStep:
         """Hand-written backward into the flat fp32 gradient buffer. Sharded runs (world > 1) issue each bucket's
         reduce-scatter on a side stream as soon as its last wgrad is enqueued (overlapping the rest of the backward)."""
         st, lay = self.store, self.store.layout
-        emb = "language_model.model.embed_tokens.weight"
-        if st.trainable(emb):
-            st.grad_view(emb).zero_()                              # accumulated with atomics
         if not self.comm.active:
             self._replay("bwd", self.backward_ops, graph)
             return

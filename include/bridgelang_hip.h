@@ -183,6 +183,12 @@ int bl_cross_entropy_backward_f32(const float* logits, int64_t ld, int32_t rows,
 int bl_rmsnorm_backward_bf16(const bl_bf16* x, int64_t ldx, const bl_bf16* w, const bl_bf16* dy, int64_t lddy,
                              const bl_bf16* dres, int64_t lddres, bl_bf16* dx, int64_t lddx, float* dw, float* partial_ws,
                              int64_t partial_ws_floats, int32_t rows, int32_t dim, float eps, void* stream);
+/* timm nn.LayerNorm backward (vision towers, stages vla-full-train / sandwich): as above with the mean removed;
+ * db = column sums of dy. partial_ws needs >= 2 * ceil(rows / rpb) * dim floats for some rpb in {8, 16, ...}. */
+int bl_layernorm_backward_bf16(const bl_bf16* x, int64_t ldx, const bl_bf16* w, const bl_bf16* dy, int64_t lddy,
+                               const bl_bf16* dres, int64_t lddres, bl_bf16* dx, int64_t lddx, float* dw, float* db,
+                               float* partial_ws, int64_t partial_ws_floats, int32_t rows, int32_t dim, float eps,
+                               void* stream);
 /* out[c] = sum_r a[r][c] (bias gradients). partial_ws >= ceil(rows/256)*cols floats. */
 int bl_colsum_bf16(const bl_bf16* a, int64_t lda, int32_t rows, int32_t cols, float* out, float* partial_ws,
                    int64_t partial_ws_floats, void* stream);
@@ -207,6 +213,17 @@ int bl_clip_coef_f32(const float* partial, int32_t n, float max_norm, float* out
  * (optional) receives the bf16 copy of the updated weights. */
 int bl_adamw_f32(float* p, float* m, float* v, const float* g, const float* norm_coef, int64_t n, float lr, float beta1,
                  float beta2, float eps, float weight_decay, int32_t step, bl_bf16* p_bf16, void* stream);
+/* timm LayerScale (patched to `scale_factor`, modeling_prismatic.py:52-59) around a residual branch, training form:
+ * y = bf16(bf16(u * scale) + res) with the branch output u kept; backward du = dy * scale, dscale = sum_rows dy * u
+ * (partial_ws >= ceil(rows / 64) * cols floats). */
+int bl_scale_residual_bf16(const bl_bf16* u, int64_t ldu, const bl_bf16* scale, const bl_bf16* res, int64_t ldres, bl_bf16* y,
+                           int64_t ldy, int64_t rows, int32_t cols, void* stream);
+int bl_layerscale_backward_bf16(const bl_bf16* dy, int64_t lddy, const bl_bf16* u, int64_t ldu, const bl_bf16* scale,
+                                bl_bf16* du, int64_t lddu, float* dscale, float* partial_ws, int64_t partial_ws_floats,
+                                int32_t rows, int32_t cols, void* stream);
+/* Device memset / device-to-device copy on `stream` (replayable steps of the training plans). */
+int bl_memset_zero(void* dst, int64_t bytes, void* stream);
+int bl_copy_bytes(void* dst, const void* src, int64_t bytes, void* stream);
 /* Row gather (scatter = 0: dst[r] = src[map(r)]) or scatter (dst[map(r)] = src[r]) with
  * map(r) = (r / group) * stride + offset + r % group — the 256 projected patch rows inside the [B, S, D] embedding
  * buffer (modeling_prismatic.py:343-351) for the projector's backward. */

@@ -210,3 +210,31 @@ def test_attention_backward(dev, hd, H, S, causal, masked):
     for i, n in enumerate(lens):
         for j, nm in enumerate("qkv"):
             grad_close(got[i, :n, j], ref[i, :n, j], f"d{nm} b={i}", tol=2.5e-2)
+
+
+@pytest.mark.parametrize("rows,dim", [(261 * 2, 256), (300, 1152)])
+def test_layernorm_and_layerscale_backward(dev, rows, dim):
+    from bridgelang_amd import train_ops as T
+    x, w, b = rand_bf16((rows, dim), 1, 2.0), P.rb(rand_bf16((dim,), 2, 0.02) + 1), rand_bf16((dim,), 5, 0.02)
+    dy, dres = rand_bf16((rows, dim), 3), rand_bf16((rows, dim), 4)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    (R.layernorm(P, xr, wr, br, 1e-6) * dy).sum().backward()
+    dx = torch.empty(rows, dim, dtype=torch.bfloat16, device=dev)
+    dw, db = torch.empty(dim, device=dev), torch.empty(dim, device=dev)
+    ws = torch.empty(2 * ((rows + 15) // 16) * dim, device=dev)
+    T.layernorm_backward(dv(x, dev), dv(w, dev), dv(dy, dev), dx, dw, db, ws, 1e-6, dres=dv(dres, dev))
+    grad_close(dx, xr.grad + dres, "layernorm dx (+residual)")
+    grad_close(dw, wr.grad, "layernorm dw")
+    grad_close(db, br.grad, "layernorm db")
+    # LayerScale residual: y = rb(rb(u * ls) + res)
+    u, ls, res = rand_bf16((rows, dim), 6), P.rb(rand_bf16((dim,), 7, 0.02) + 0.1), rand_bf16((rows, dim), 8)
+    ur, lr_ = u.clone().requires_grad_(True), ls.clone().requires_grad_(True)
+    y = P.rb(P.rb(ur * lr_) + res)
+    (y * dy).sum().backward()
+    Y = torch.empty(rows, dim, dtype=torch.bfloat16, device=dev)
+    T.scale_residual(dv(u, dev), dv(ls, dev), dv(res, dev), Y)
+    assert torch.equal(Y.cpu().float(), y.detach())
+    du, dls = torch.empty_like(Y), torch.empty(dim, device=dev)
+    T.layerscale_backward(dv(dy, dev), dv(u, dev), dv(ls, dev), du, dls, torch.empty(((rows + 63) // 64) * dim, device=dev))
+    grad_close(du, ur.grad, "layerscale du")
+    grad_close(dls, lr_.grad, "layerscale dscale")

@@ -39,7 +39,7 @@ def cos(a, b):
     return (a @ b / (a.norm() * b.norm() + 1e-300)).item()
 
 
-@pytest.mark.parametrize("stage", ["vla-train", "vla-last-layer-train", "align"])
+@pytest.mark.parametrize("stage", ["vla-train", "vla-last-layer-train", "align", "vla-full-train", "vla-sandwich-train"])
 def test_gradients_match_autograd(dev, stage):
     from bridgelang_amd.training.step import TrainStep, trainable_names
     from bridgelang_amd.weights import allocate, tiny_dims
