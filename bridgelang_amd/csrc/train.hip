@@ -323,6 +323,28 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const uint16_t* dy,
   for (int e = 0; e < 8; ++e) partial[(long)blockIdx.x * cols + col8 + e] = acc[e];
 }
 
+// ---- LoRA helpers (vla-scripts/finetune.py:174-189) ----
+// out = bf16(s · x) on a small [T, R] tensor (the scaling alpha / r applied once to t and to dt)
+__global__ void scale_bf16_kernel(const uint16_t* x, float s, uint16_t* out, long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    unpack8(*(const u32x4_t*)(x + i * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= s;
+    *(u32x4_t*)(out + i * 8) = pack8(v);
+  }
+}
+// fused adapters (q‖k‖v, interleaved gate/up): zero dB[n][c] unless column block c / rp belongs to row n's member
+__global__ void lora_block_mask_kernel(float* g, int n_rows, int R, int rp, int members, int interleave) {
+  const long total = (long)n_rows * R;
+  const int rows_per_member = n_rows / members;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / R), c = (int)(i - (long)n * R);
+    const int mem = interleave ? (n % members) : (n / rows_per_member);
+    if (c / rp != mem) g[i] = 0.f;
+  }
+}
+
 // ---- row gather / scatter: out row r ↔ src row (r / group) * stride + offset + r % group (the projector's 256 patch rows
 //      inside the [B, S, D] embedding buffer) ----
 __global__ void map_rows_kernel(const uint16_t* src, long lds_, uint16_t* dst, long ldd, long rows, int cols, int group,
@@ -526,6 +548,25 @@ extern "C" int bl_memset_zero(void* dst, int64_t bytes, void* stream) {
 extern "C" int bl_copy_bytes(void* dst, const void* src, int64_t bytes, void* stream) {
   if (!dst || !src || bytes <= 0) return BL_E_ARG;
   return hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? BL_OK : BL_E_LAUNCH;
+}
+
+extern "C" int bl_scale_bf16(const bl_bf16* x, float s, bl_bf16* out, int64_t n, void* stream) {
+  if (!x || !out) return BL_E_ARG;
+  if (n <= 0 || (n % 8)) return BL_E_SHAPE;
+  if (!bl_aligned16(x) || !bl_aligned16(out)) return BL_E_ALIGN;
+  hipLaunchKernelGGL(scale_bf16_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, s, out, (long)(n / 8));
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_lora_block_mask_f32(float* g, int32_t n_rows, int32_t R, int32_t rp, int32_t members, int32_t interleave,
+                                      void* stream) {
+  if (!g) return BL_E_ARG;
+  if (n_rows <= 0 || R <= 0 || rp <= 0 || members <= 0 || R != rp * members || (n_rows % members)) return BL_E_SHAPE;
+  hipLaunchKernelGGL(lora_block_mask_kernel, dim3(grid_for((long)n_rows * R, 256)), dim3(256), 0, (hipStream_t)stream, g,
+                     n_rows, R, rp, members, interleave);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
 }
 
 extern "C" int bl_colsum_bf16(const bl_bf16* a, int64_t lda, int32_t rows, int32_t cols, float* out, float* partial_ws,

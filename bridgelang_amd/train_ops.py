@@ -186,3 +186,14 @@ def fill_zero(t: torch.Tensor, run: bool = True) -> Op:
 def copy_f32(src: torch.Tensor, dst: torch.Tensor, run: bool = True) -> Op:
     assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel() and src.dtype == dst.dtype
     return _op("bl_copy_bytes", (dst.data_ptr(), src.data_ptr(), src.numel() * src.element_size()), (src, dst), run)
+
+
+def scale(x: torch.Tensor, s: float, out: torch.Tensor, run: bool = True) -> Op:
+    assert x.is_contiguous() and out.is_contiguous() and x.numel() == out.numel()
+    return _op("bl_scale_bf16", (_bf16(x, "x").data_ptr(), float(s), _bf16(out, "out").data_ptr(), x.numel()), (x, out), run)
+
+
+def lora_block_mask(g: torch.Tensor, rp: int, members: int, interleave: bool, run: bool = True) -> Op:
+    n, R = g.shape
+    assert g.is_contiguous()
+    return _op("bl_lora_block_mask_f32", (_f32(g, "g").data_ptr(), n, R, rp, members, int(interleave)), (g,), run)

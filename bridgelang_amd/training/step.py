@@ -37,6 +37,7 @@ STAGES: Dict[str, Tuple[bool, bool, str]] = {
     "full-finetune": (True, True, "all"), "vla-full-train": (True, True, "all"),
     "last-layer-finetune": (False, False, "last"), "vla-last-layer-train": (False, False, "last"),
     "vla-sandwich-train": (True, True, "last"),
+    "lora": (False, False, "none"),          # vla-scripts/finetune.py: base frozen, adapters train (training/lora.py)
 }
 
 
@@ -86,7 +87,10 @@ class ParamStore:
     """Trainable tensors as one flat parameter space (sharding.ShardLayout): full fp32 gradients and a full bf16 staging
     copy on every rank, fp32 masters and AdamW moments for this rank's 1/world slice of every bucket only."""
 
-    def __init__(self, w: VLAWeights, stage: str, world: int = 1, rank: int = 0):
+    def __init__(self, w: VLAWeights, stage: str, world: int = 1, rank: int = 0,
+                 extra: Optional[List[Tuple[str, torch.Tensor, bool, str]]] = None):
+        """`extra`: additional trainable bf16 tensors outside the model's own table — (name, flat live tensor, decayed,
+        bucket key), e.g. LoRA adapters."""
         self.w, self.stage = w, stage
         specs = w._specs()
         names = set(trainable_names(w, stage))
@@ -122,6 +126,16 @@ class ParamStore:
                 u.offset = lay.add(u.numel, len(self.units))
                 self.units.append(u)
                 self.by_name[name] = u
+        cur = None
+        for name, dst, decay, bkey in (extra or []):
+            if bkey != cur:
+                lay.begin(bkey, decay)
+                cur = bkey
+            assert dst.is_contiguous() and dst.dtype == torch.bfloat16 and lay.buckets[-1].decay == decay
+            u = Unit(name, 0, dst.numel(), None, dst.view(-1), decay, len(lay.buckets) - 1, (name,))
+            u.offset = lay.add(u.numel, len(self.units))
+            self.units.append(u)
+            self.by_name[name] = u
         lay.close()
         self.total = lay.total
         self.n_params = sum(u.numel for u in self.units)
@@ -156,7 +170,10 @@ class ParamStore:
         return sl.view(u.group.n, u.group.k) if u.group is not None else sl
 
     def _named(self, flat: torch.Tensor, name: str) -> torch.Tensor:
-        u, pl = self.by_name[name], self.w.placements[name]
+        u = self.by_name[name]
+        if name not in self.w.placements:                       # extra unit: flat
+            return flat[u.offset:u.offset + u.numel]
+        pl = self.w.placements[name]
         shape = self.w._specs()[name].shape
         if u.group is None:
             return flat[u.offset:u.offset + u.numel].view(shape)
@@ -200,15 +217,21 @@ class TrainStep:
 
     def __init__(self, weights: VLAWeights, stage: str, batch: int, prompt_len: int, *, max_grad_norm: float = 1.0,
                  weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8, store: Optional[ParamStore] = None,
-                 world: int = 1, rank: int = 0, group=None, reduce_dtype: torch.dtype = torch.float32):
-        self.train_vision = STAGES[stage][0]
+                 world: int = 1, rank: int = 0, group=None, reduce_dtype: torch.dtype = torch.float32, lora=None):
+        """`lora`: a training.lora.LoraAdapters → stage "lora": the base model is frozen and only the adapters train."""
+        if (lora is not None) != (stage == "lora"):
+            raise ValueError("stage 'lora' and the `lora` adapters go together")
+        self.lora = lora
+        self.train_vision = STAGES[stage][0] or lora is not None      # towers need their training-form forward
         self.w, self.dims, self.stage = weights, weights.dims, stage
         d = self.dims
         self.B, self.L, self.S = batch, prompt_len, prompt_len + d.n_patches
         if self.S > 320:
             raise ValueError("training sequences are limited to 320 positions (whole-sequence attention kernels)")
         self.max_grad_norm, self.weight_decay, self.betas, self.eps = max_grad_norm, weight_decay, betas, eps
-        self.store = store if store is not None else ParamStore(weights, stage, world, rank)
+        if store is None:
+            store = ParamStore(weights, stage, world, rank, extra=lora.plain_units() if lora is not None else None)
+        self.store = store
         assert self.store.stage == stage
         st = self.store
         self.comm = ShardComm(st.layout, group, reduce_dtype)
@@ -231,7 +254,7 @@ class TrainStep:
         self.feats = self._vis.feats
         # ---- saved activations ----
         Pv = 4 * d.vision_dim
-        self.z1, self.p1, self.z2, self.p2 = z(B * 256, Pv), z(B * 256, Pv), z(B * 256, D), z(B * 256, D)
+        self.z1, self.p1, self.z2, self.p2, self.p3 = z(B * 256, Pv), z(B * 256, Pv), z(B * 256, D), z(B * 256, D), z(B * 256, D)
         self.x = [z(Tn, D) for _ in range(NL + 1)]            # residual stream entering layer l (x[NL] = final)
         self.xm = [z(Tn, D) for _ in range(NL)]
         self.h1, self.h2 = [z(Tn, D) for _ in range(NL)], [z(Tn, D) for _ in range(NL)]
@@ -258,7 +281,8 @@ class TrainStep:
         dv_ = max((tw.dims.dim for tw in towers), default=0)
         self.norm_ws = z(max(((Tn + 15) // 16) * D, 2 * ((mv + 15) // 16) * dv_), dtype=torch.float32)
         self.col_ws = z(max(((Tn + 255) // 256) * max(Pv, D), 256 * dv_, ((mv + 63) // 64) * dv_ * 4), dtype=torch.float32)
-        self._frozen_dw = z(max(D, Pv), dtype=torch.float32)                  # sink for norm-weight grads of frozen norms
+        self._frozen_dw = z(2 * max(D, Pv, dv_), dtype=torch.float32)         # sink for vector grads of frozen tensors
+        self._lora_t: Dict[int, torch.Tensor] = {}                            # saved t = x·Aᵀ per adapted linear
         self.dfeats = z(B * 256, d.vision_dim) if self.train_vision else None
         self.vis = [self._alloc_tower(tw) for tw in towers]
         # ---- transposed weights for dgrad ----
@@ -267,6 +291,8 @@ class TrainStep:
         for tw, sv, col in zip(towers, self.vis, (0, d.dino.dim)):
             self.vision_forward_ops += self._plan_tower_forward(tw, col, sv)
         self.forward_ops = self._plan_forward()
+        tmax = max((t.numel() for t in self._lora_t.values()), default=8)
+        self._lora_tmp, self._lora_tmp2 = z(tmax), z(tmax)
         self._ready: List[Tuple[int, str]] = []      # (number of backward ops enqueued, bucket key complete at that point)
         self.backward_ops = self._plan_backward()
         self.repack_ops = self._plan_repack()
@@ -285,25 +311,71 @@ class TrainStep:
     def _dgrad(self, dy: torch.Tensor, packed: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, **kw) -> Op:
         return ops.gemm(dy, self.wT(packed), out, epilogue, run=False, **kw)
 
-    def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, packed: torch.Tensor) -> List[Op]:
-        """dW[N, K] = dyᵀ[N, T] · x[T, K] as the NT GEMM over token-padded transposes; [] when the weight is frozen."""
-        u = self.store.unit_of_packed(packed)
-        if u is None:
-            return []
+    def _wgrad_into(self, dy: torch.Tensor, x: torch.Tensor, gview: torch.Tensor) -> List[Op]:
+        """gview[N, K] (fp32) = dyᵀ[N, T] · x[T, K] as the NT GEMM over token-padded transposes."""
         Tn, N = dy.shape
         K = x.shape[1]
-        assert (N, K) == (u.group.n, u.group.k), (dy.shape, x.shape, u.group.n, u.group.k)
+        assert tuple(gview.shape) == (N, K), (dy.shape, x.shape, gview.shape)
         Tp = (Tn + 63) // 64 * 64
         assert max(N, K) * Tp <= self.tA.numel()
         tA = self.tA[:N * Tp].view(N, Tp)
         tB = self.tB[:K * Tp].view(K, Tp)
         tBp = self.tBp[:K * Tp].view(K // 16, Tp // 32, 64, 8)
         return [T.transpose_pad(dy, tA, Tp, run=False), T.transpose_pad(x, tB, Tp, run=False),
-                T.pack(tB, tBp, run=False), ops.gemm(tA, tBp, self.store.grad_view(u), EPI_F32, algo_nk=(K, Tn), run=False)]
+                T.pack(tB, tBp, run=False), ops.gemm(tA, tBp, gview, EPI_F32, algo_nk=(K, Tn), run=False)]
+
+    def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, packed: torch.Tensor) -> List[Op]:
+        """Weight gradient of a base linear; [] when the weight is frozen."""
+        u = self.store.unit_of_packed(packed)
+        return [] if u is None else self._wgrad_into(dy, x, self.store.grad_view(u))
+
+    def _lin(self, x: torch.Tensor, packed: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, **kw) -> List[Op]:
+        """Forward of one nn.Linear: the base GEMM, plus the LoRA branch y += s·(x Aᵀ) Bᵀ when it carries an adapter."""
+        plan = [ops.gemm(x, packed, out, epilogue, run=False, **kw)]
+        ad = self.lora.get(packed) if self.lora is not None else None
+        if ad is not None:
+            assert "out_map" not in kw, "row-mapped outputs carry no adapter"
+            t = torch.zeros(x.shape[0], ad.R, dtype=torch.bfloat16, device=self.device)
+            self._lora_t[packed.data_ptr()] = t
+            n = ad.group.n
+            plan += [ops.gemm(x, ad.A_p, t, EPI_NONE, run=False),
+                     ops.gemm(t, ad.B_p, out, ops.EPI_BIAS_RES, bias=self.lora.zero_vec[:n], scale=self.lora.scale_vec[:n],
+                              res=out, run=False)]
+        return plan
+
+    def _lin_bwd(self, dy: torch.Tensor, x: torch.Tensor, packed: torch.Tensor, dx: Optional[torch.Tensor]) -> List[Op]:
+        """Backward of one nn.Linear given dy: base wgrad (if trainable), dx = dy·W (if wanted), adapter grads and the
+        adapter's share of dx."""
+        plan = self._wgrad(dy, x, packed)
+        if dx is not None:
+            plan.append(self._dgrad(dy, packed, dx))
+        ad = self.lora.get(packed) if self.lora is not None else None
+        if ad is None:
+            return plan
+        i = ad.index
+        st, s, R = self.store, self.lora.scaling, ad.R
+        t = self._lora_t[packed.data_ptr()]
+        ts = self._lora_tmp[:t.numel()].view(t.shape)
+        dt = self._lora_tmp2[:t.numel()].view(t.shape)
+        gB = st.grad_view(f"lora.{i}.B").view(ad.group.n, R)
+        gA = st.grad_view(f"lora.{i}.A").view(R, ad.group.k)
+        plan.append(T.scale(t, s, ts, run=False))
+        plan += self._wgrad_into(dy, ts, gB)
+        if len(ad.modules) > 1:
+            plan.append(T.lora_block_mask(gB, R // len(ad.modules), len(ad.modules), ad.mode == "interleave", run=False))
+        plan += [self._dgrad(dy, ad.B_p, dt), T.scale(dt, s, dt, run=False)]
+        plan += self._wgrad_into(dt, x, gA)
+        if dx is not None:
+            plan.append(self._dgrad(dt, ad.A_p, dx, EPI_RES, res=dx))
+        return plan
 
     def _gvec(self, name: str, n: int) -> torch.Tensor:
         """fp32 gradient slot of a vector parameter, or a scratch sink when it is frozen."""
         return self.store.grad_view(name) if self.store.trainable(name) else self._frozen_dw[:n]
+
+    def _bias_grad(self, dy: torch.Tensor, name: str) -> List[Op]:
+        """Bias gradient = column sums of dy; nothing when the bias is frozen."""
+        return [T.colsum(dy, self.store.grad_view(name), self.col_ws, run=False)] if self.store.trainable(name) else []
 
     # ---- plans --------------------------------------------------------------------------------------------------
     def _plan_forward(self) -> List[Op]:
@@ -312,24 +384,23 @@ class TrainStep:
         g = lambda *a, **k: ops.gemm(*a, run=False, **k)
         plan: List[Op] = []
         # projector with the pre-activations kept (modeling_prismatic.py:151-156)
-        plan += [g(self.feats, w.fc1_w, self.z1, EPI_BIAS, bias=w.fc1_b), T.gelu(self.z1, self.p1, run=False),
-                 g(self.p1, w.fc2_w, self.z2, EPI_BIAS, bias=w.fc2_b), T.gelu(self.z2, self.p2, run=False),
-                 g(self.p2, w.fc3_w, self.x[0], EPI_BIAS, bias=w.fc3_b, out_map=(256, S, 1)),
+        lin = self._lin
+        plan += lin(self.feats, w.fc1_w, self.z1, EPI_BIAS, bias=w.fc1_b) + [T.gelu(self.z1, self.p1, run=False)]
+        plan += lin(self.p1, w.fc2_w, self.z2, EPI_BIAS, bias=w.fc2_b) + [T.gelu(self.z2, self.p2, run=False)]
+        plan += lin(self.p2, w.fc3_w, self.p3, EPI_BIAS, bias=w.fc3_b)
+        plan += [T.map_rows(self.p3, self.x[0], rows=B * 256, group=256, stride=S, offset=1, scatter=True, run=False),
                  ops.embed_splice(self.input_ids, w.embed, self.x[0].view(B, S, D), d.n_patches, run=False)]
         st = (S * 3 * D, hd, 3 * D)
         for l, lw in enumerate(w.layers):
             x, xm, qkv = self.x[l], self.xm[l], self.qkv[l]
-            plan += [ops.rmsnorm(x, lw.ln1, self.h1[l], d.rms_eps, run=False),
-                     g(self.h1[l], lw.qkv_w, qkv, EPI_NONE),
-                     T.rope(qkv, self.cos, self.sin, B=B, S=S, H=H, head_dim=hd, run=False),
+            plan += [ops.rmsnorm(x, lw.ln1, self.h1[l], d.rms_eps, run=False)] + lin(self.h1[l], lw.qkv_w, qkv, EPI_NONE)
+            plan += [T.rope(qkv, self.cos, self.sin, B=B, S=S, H=H, head_dim=hd, run=False),
                      T.attention_lse(qkv, qkv[:, D:], qkv[:, 2 * D:], self.ao[l], self.lse[l], B=B, H=H, Sq=S, Skv=S,
                                      head_dim=hd, q_strides=st, k_strides=st, v_strides=st, o_strides=(S * D, hd, D),
-                                     causal=True, key_mask=self.key_mask, run=False),
-                     g(self.ao[l], lw.o_w, xm, EPI_RES, res=x),
-                     ops.rmsnorm(xm, lw.ln2, self.h2[l], d.rms_eps, run=False),
-                     g(self.h2[l], lw.gu_w, self.gu[l], EPI_NONE),
-                     T.swiglu(self.gu[l], self.act[l], run=False),
-                     g(self.act[l], lw.down_w, self.x[l + 1], EPI_RES, res=xm)]
+                                     causal=True, key_mask=self.key_mask, run=False)]
+            plan += lin(self.ao[l], lw.o_w, xm, EPI_RES, res=x)
+            plan += [ops.rmsnorm(xm, lw.ln2, self.h2[l], d.rms_eps, run=False)] + lin(self.h2[l], lw.gu_w, self.gu[l], EPI_NONE)
+            plan += [T.swiglu(self.gu[l], self.act[l], run=False)] + lin(self.act[l], lw.down_w, self.x[l + 1], EPI_RES, res=xm)
         plan += [ops.rmsnorm(self.x[-1], w.norm, self.hn, d.rms_eps, run=False),
                  g(self.hn, w.lm_head, self.logits, EPI_F32_BF16R),
                  ops.cross_entropy(self.logits, self.targets, self.row_loss, self.mean_cnt, IGNORE_INDEX, run=False)]
@@ -343,6 +414,7 @@ class TrainStep:
         plan += self._wgrad(self.dlogits, self.hn, w.lm_head)
         self._ready.append((len(plan), "llm.lm_head"))
         plan.append(self._dgrad(self.dlogits, w.lm_head, self.dh))
+        lb = self._lin_bwd
         dx, dx2 = self.dxa, self.dxb
         plan.append(T.rmsnorm_backward(self.x[-1], w.norm, self.dh, dx, self._gvec(f"{lm}.norm.weight", D), self.norm_ws,
                                        d.rms_eps, run=False))
@@ -350,24 +422,20 @@ class TrainStep:
         stop_layer = self._lowest_needed_layer()
         for l in range(d.llm_layers - 1, stop_layer - 1, -1):
             lw, b = w.layers[l], f"{lm}.layers.{l}"
-            plan += self._wgrad(dx, self.act[l], lw.down_w)
-            plan.append(self._dgrad(dx, lw.down_w, self.dact))
+            plan += lb(dx, self.act[l], lw.down_w, self.dact)
             plan.append(T.swiglu_backward(self.gu[l], self.dact, self.dgu, run=False))
-            plan += self._wgrad(self.dgu, self.h2[l], lw.gu_w)
-            plan.append(self._dgrad(self.dgu, lw.gu_w, self.dh))
+            plan += lb(self.dgu, self.h2[l], lw.gu_w, self.dh)
             plan.append(T.rmsnorm_backward(self.xm[l], lw.ln2, self.dh, dx2, self._gvec(f"{b}.post_attention_layernorm.weight", D),
                                            self.norm_ws, d.rms_eps, dres=dx, run=False))
-            plan += self._wgrad(dx2, self.ao[l], lw.o_w)
-            plan.append(self._dgrad(dx2, lw.o_w, self.dao))
+            plan += lb(dx2, self.ao[l], lw.o_w, self.dao)
             qkv, dq = self.qkv[l], self.dqkv
             plan.append(T.attention_backward(qkv, qkv[:, D:], qkv[:, 2 * D:], self.ao[l], self.dao, self.lse[l], self.delta,
                                              dq, dq[:, D:], dq[:, 2 * D:], B=B, H=H, Sq=S, Skv=S, head_dim=hd,
                                              q_strides=strides, k_strides=strides, v_strides=strides,
                                              o_strides=(S * D, hd, D), causal=True, key_mask=self.key_mask, run=False))
             plan.append(T.rope_backward(dq, self.cos, self.sin, B=B, S=S, H=H, head_dim=hd, run=False))
-            plan += self._wgrad(dq, self.h1[l], lw.qkv_w)
+            plan += lb(dq, self.h1[l], lw.qkv_w, self.dh)
             self._ready.append((len(plan), f"llm.layer{l:02d}"))
-            plan.append(self._dgrad(dq, lw.qkv_w, self.dh))
             plan.append(T.rmsnorm_backward(self.x[l], lw.ln1, self.dh, dx, self._gvec(f"{b}.input_layernorm.weight", D),
                                            self.norm_ws, d.rms_eps, dres=dx2, run=False))
         if stop_layer > 0:
@@ -377,21 +445,18 @@ class TrainStep:
             plan.append(T.fill_zero(st.grad_view(f"{lm}.embed_tokens.weight"), run=False))     # accumulated with atomics
             plan.append(T.embed_backward(self.input_ids, dx.view(B, S, D), st.grad_view(f"{lm}.embed_tokens.weight").view(d.vocab, D),
                                          d.n_patches, run=False))
-        if st.trainable("projector.fc3.weight"):
+        if st.trainable("projector.fc3.weight") or self.lora is not None:
             plan.append(T.map_rows(dx, self.dp3, rows=B * 256, group=256, stride=S, offset=1, scatter=False, run=False))
-            plan.append(T.colsum(self.dp3, st.grad_view("projector.fc3.bias"), self.col_ws, run=False))
-            plan += self._wgrad(self.dp3, self.p2, w.fc3_w)
-            plan.append(self._dgrad(self.dp3, w.fc3_w, self.dp2))
+            plan += self._bias_grad(self.dp3, "projector.fc3.bias")
+            plan += lb(self.dp3, self.p2, w.fc3_w, self.dp2)
             plan.append(T.gelu_backward(self.z2, self.dp2, self.dz2, run=False))
-            plan.append(T.colsum(self.dz2, st.grad_view("projector.fc2.bias"), self.col_ws, run=False))
-            plan += self._wgrad(self.dz2, self.p1, w.fc2_w)
-            plan.append(self._dgrad(self.dz2, w.fc2_w, self.dp1))
+            plan += self._bias_grad(self.dz2, "projector.fc2.bias")
+            plan += lb(self.dz2, self.p1, w.fc2_w, self.dp1)
             plan.append(T.gelu_backward(self.z1, self.dp1, self.dz1, run=False))
-            plan.append(T.colsum(self.dz1, st.grad_view("projector.fc1.bias"), self.col_ws, run=False))
-            plan += self._wgrad(self.dz1, self.feats, w.fc1_w)
+            plan += self._bias_grad(self.dz1, "projector.fc1.bias")
+            plan += lb(self.dz1, self.feats, w.fc1_w, self.dfeats if self.train_vision else None)
             self._ready.append((len(plan), "projector"))
             if self.train_vision:
-                plan.append(self._dgrad(self.dz1, w.fc1_w, self.dfeats))
                 for tw, sv, col in zip((w.dino, w.siglip), self.vis, (0, d.dino.dim)):
                     plan += self._plan_tower_backward(tw, col, sv, len(plan))
         return plan
@@ -426,24 +491,24 @@ class TrainStep:
         st = (Tk * 3 * Dm, hd, 3 * Dm)
         for i, b in enumerate(tw.blocks):
             x, xm, qkv = sv["x"][i], sv["xm"][i], sv["qkv"][i]
-            plan += [ops.layernorm(x, b.norm1_w, b.norm1_b, sv["h1"][i], eps, run=False),
-                     g(sv["h1"][i], b.qkv_w, qkv, EPI_BIAS, bias=b.qkv_b),
-                     T.attention_lse(qkv, qkv[:, Dm:], qkv[:, 2 * Dm:], sv["ao"][i], sv["lse"][i], B=B, H=t.heads, Sq=Tk,
+            plan += [ops.layernorm(x, b.norm1_w, b.norm1_b, sv["h1"][i], eps, run=False)]
+            plan += self._lin(sv["h1"][i], b.qkv_w, qkv, EPI_BIAS, bias=b.qkv_b)
+            plan += [T.attention_lse(qkv, qkv[:, Dm:], qkv[:, 2 * Dm:], sv["ao"][i], sv["lse"][i], B=B, H=t.heads, Sq=Tk,
                                      Skv=Tk, head_dim=hd, q_strides=st, k_strides=st, v_strides=st,
                                      o_strides=(Tk * Dm, hd, Dm), causal=False, run=False)]
             if b.ls1 is not None:
-                plan += [g(sv["ao"][i], b.proj_w, sv["u1"][i], EPI_BIAS, bias=b.proj_b),
-                         T.scale_residual(sv["u1"][i], b.ls1, x, xm, run=False)]
+                plan += self._lin(sv["ao"][i], b.proj_w, sv["u1"][i], EPI_BIAS, bias=b.proj_b)
+                plan.append(T.scale_residual(sv["u1"][i], b.ls1, x, xm, run=False))
             else:
-                plan.append(g(sv["ao"][i], b.proj_w, xm, ops.EPI_BIAS_RES, bias=b.proj_b, res=x))
-            plan += [ops.layernorm(xm, b.norm2_w, b.norm2_b, sv["h2"][i], eps, run=False),
-                     g(sv["h2"][i], b.fc1_w, sv["zz"][i], EPI_BIAS, bias=b.fc1_b),
-                     T.gelu(sv["zz"][i], sv["f"][i], run=False)]
+                plan += self._lin(sv["ao"][i], b.proj_w, xm, ops.EPI_BIAS_RES, bias=b.proj_b, res=x)
+            plan.append(ops.layernorm(xm, b.norm2_w, b.norm2_b, sv["h2"][i], eps, run=False))
+            plan += self._lin(sv["h2"][i], b.fc1_w, sv["zz"][i], EPI_BIAS, bias=b.fc1_b)
+            plan.append(T.gelu(sv["zz"][i], sv["f"][i], run=False))
             if b.ls2 is not None:
-                plan += [g(sv["f"][i], b.fc2_w, sv["u2"][i], EPI_BIAS, bias=b.fc2_b),
-                         T.scale_residual(sv["u2"][i], b.ls2, xm, sv["x"][i + 1], run=False)]
+                plan += self._lin(sv["f"][i], b.fc2_w, sv["u2"][i], EPI_BIAS, bias=b.fc2_b)
+                plan.append(T.scale_residual(sv["u2"][i], b.ls2, xm, sv["x"][i + 1], run=False))
             else:
-                plan.append(g(sv["f"][i], b.fc2_w, sv["x"][i + 1], ops.EPI_BIAS_RES, bias=b.fc2_b, res=xm))
+                plan += self._lin(sv["f"][i], b.fc2_w, sv["x"][i + 1], ops.EPI_BIAS_RES, bias=b.fc2_b, res=xm)
         # tap: patch rows of the last block output → this tower's channels of the fused feature map
         plan.append(T.map_rows(sv["x"][-1], self.feats[:, feat_col:feat_col + Dm], rows=B * 256, group=256, stride=Tk,
                                offset=t.n_prefix, scatter=False, run=False))
@@ -455,7 +520,9 @@ class TrainStep:
         Tk, Dm, hd, M = t.tokens, t.dim, t.head_dim, B * t.tokens
         p = t.prefix
         tower_key = p.split(".")[1]
-        gv = lambda name: st.grad_view(name)
+        gv = lambda name: self._gvec(name, Dm)
+        gb = lambda name: st.grad_view(name) if st.trainable(name) else self._frozen_dw[Dm:2 * Dm]   # 2nd sink: LN dw + db
+        lb = self._lin_bwd
         dx, dx2 = sv["dxa"], sv["dxb"]
         plan: List[Op] = [T.fill_zero(dx, run=False),
                           T.map_rows(self.dfeats[:, feat_col:feat_col + Dm], dx, rows=B * 256, group=256, stride=Tk,
@@ -467,49 +534,48 @@ class TrainStep:
             if b.ls2 is not None:
                 plan.append(T.layerscale_backward(dx, sv["u2"][i], b.ls2, sv["du"], gv(f"{bn}.ls2.scale_factor"), self.col_ws, run=False))
                 dbr = sv["du"]
-            plan.append(T.colsum(dbr, gv(f"{bn}.mlp.fc2.bias"), self.col_ws, run=False))
-            plan += self._wgrad(dbr, sv["f"][i], b.fc2_w)
-            plan.append(self._dgrad(dbr, b.fc2_w, sv["df"]))
+            plan += self._bias_grad(dbr, f"{bn}.mlp.fc2.bias")
+            plan += lb(dbr, sv["f"][i], b.fc2_w, sv["df"])
             plan.append(T.gelu_backward(sv["zz"][i], sv["df"], sv["dz"], run=False))
-            plan.append(T.colsum(sv["dz"][:, :t.mlp], gv(f"{bn}.mlp.fc1.bias"), self.col_ws, run=False))
-            plan += self._wgrad(sv["dz"], sv["h2"][i], b.fc1_w)
-            plan.append(self._dgrad(sv["dz"], b.fc1_w, sv["dh"]))
-            plan.append(T.layernorm_backward(sv["xm"][i], b.norm2_w, sv["dh"], dx2, gv(f"{bn}.norm2.weight"), gv(f"{bn}.norm2.bias"),
+            plan += self._bias_grad(sv["dz"][:, :t.mlp], f"{bn}.mlp.fc1.bias")
+            plan += lb(sv["dz"], sv["h2"][i], b.fc1_w, sv["dh"])
+            plan.append(T.layernorm_backward(sv["xm"][i], b.norm2_w, sv["dh"], dx2, gv(f"{bn}.norm2.weight"), gb(f"{bn}.norm2.bias"),
                                              self.norm_ws, eps, dres=dx, run=False))
             dbr = dx2
             if b.ls1 is not None:
                 plan.append(T.layerscale_backward(dx2, sv["u1"][i], b.ls1, sv["du"], gv(f"{bn}.ls1.scale_factor"), self.col_ws, run=False))
                 dbr = sv["du"]
-            plan.append(T.colsum(dbr, gv(f"{bn}.attn.proj.bias"), self.col_ws, run=False))
-            plan += self._wgrad(dbr, sv["ao"][i], b.proj_w)
-            plan.append(self._dgrad(dbr, b.proj_w, sv["dao"]))
+            plan += self._bias_grad(dbr, f"{bn}.attn.proj.bias")
+            plan += lb(dbr, sv["ao"][i], b.proj_w, sv["dao"])
             qkv, dq = sv["qkv"][i], sv["dqkv"]
             plan.append(T.attention_backward(qkv, qkv[:, Dm:], qkv[:, 2 * Dm:], sv["ao"][i], sv["dao"], sv["lse"][i], sv["delta"],
                                              dq, dq[:, Dm:], dq[:, 2 * Dm:], B=B, H=t.heads, Sq=Tk, Skv=Tk, head_dim=hd,
                                              q_strides=strides, k_strides=strides, v_strides=strides,
                                              o_strides=(Tk * Dm, hd, Dm), causal=False, run=False))
-            plan.append(T.colsum(dq, gv(f"{bn}.attn.qkv.bias"), self.col_ws, run=False))
-            plan += self._wgrad(dq, sv["h1"][i], b.qkv_w)
+            plan += self._bias_grad(dq, f"{bn}.attn.qkv.bias")
+            plan += lb(dq, sv["h1"][i], b.qkv_w, sv["dh"])
             self._ready.append((base + len(plan), f"vision.{tower_key}.block{i:02d}"))
-            plan.append(self._dgrad(dq, b.qkv_w, sv["dh"]))
-            plan.append(T.layernorm_backward(sv["x"][i], b.norm1_w, sv["dh"], dx, gv(f"{bn}.norm1.weight"), gv(f"{bn}.norm1.bias"),
+            plan.append(T.layernorm_backward(sv["x"][i], b.norm1_w, sv["dh"], dx, gv(f"{bn}.norm1.weight"), gb(f"{bn}.norm1.bias"),
                                              self.norm_ws, eps, dres=dx2, run=False))
         # stem: dx = gradient of [prefix tokens | patch embeddings + pos]
-        dxv = dx.view(B, Tk * Dm)
-        plan.append(T.colsum(dxv[:, t.n_prefix * Dm:], gv(f"{p}.pos_embed"), self.col_ws, run=False))
-        if t.n_prefix:
-            plan.append(T.colsum(dxv[:, :t.n_prefix * Dm], sv["tok"], self.col_ws, run=False))
-            plan.append(T.copy_f32(sv["tok"][:Dm], gv(f"{p}.cls_token"), run=False))
-            plan.append(T.copy_f32(sv["tok"][Dm:t.n_prefix * Dm], gv(f"{p}.reg_token"), run=False))
-        plan.append(T.map_rows(dx, sv["dpe"], rows=B * 256, group=256, stride=Tk, offset=t.n_prefix, scatter=False, run=False))
-        plan.append(T.colsum(sv["dpe"], gv(f"{p}.patch_embed.proj.bias"), self.col_ws, run=False))
-        plan += self._wgrad(sv["dpe"], self._vis.vbuf[1 if feat_col else 0]["col"], tw.patch_w)
+        if st.trainable(f"{p}.pos_embed"):
+            dxv = dx.view(B, Tk * Dm)
+            plan.append(T.colsum(dxv[:, t.n_prefix * Dm:], st.grad_view(f"{p}.pos_embed"), self.col_ws, run=False))
+            if t.n_prefix:
+                plan.append(T.colsum(dxv[:, :t.n_prefix * Dm], sv["tok"], self.col_ws, run=False))
+                plan.append(T.copy_f32(sv["tok"][:Dm], st.grad_view(f"{p}.cls_token"), run=False))
+                plan.append(T.copy_f32(sv["tok"][Dm:t.n_prefix * Dm], st.grad_view(f"{p}.reg_token"), run=False))
+            plan.append(T.map_rows(dx, sv["dpe"], rows=B * 256, group=256, stride=Tk, offset=t.n_prefix, scatter=False, run=False))
+            plan += self._bias_grad(sv["dpe"], f"{p}.patch_embed.proj.bias")
+            plan += self._wgrad(sv["dpe"], self._vis.vbuf[1 if feat_col else 0]["col"], tw.patch_w)
         self._ready.append((base + len(plan), f"vision.{tower_key}.stem"))
         return plan
 
     def _lowest_needed_layer(self) -> int:
         """Backward stops above the lowest decoder layer that still has a trainable tensor below or inside it."""
         names = self.store.names
+        if self.lora is not None:
+            return 0
         if any(not n.startswith("language_model.model.layers.") and not n.startswith("language_model.lm_head")
                and not n.startswith("language_model.model.norm") for n in names):
             return 0                     # embeddings / projector / vision sit under layer 0
@@ -520,7 +586,7 @@ class TrainStep:
         """After AdamW wrote the bf16 copy of every group's logical matrix: refresh the forward and the dgrad layouts."""
         plan: List[Op] = []
         st = self.store
-        nmax = max((u.numel for u in st.units if u.group is not None), default=8)
+        nmax = max((u.numel for u in st.units), default=8)
         self._tW = torch.zeros(nmax, dtype=torch.bfloat16, device=self.device)
         self._plain_copies = [(u.dst, st.stage_bf16[u.offset:u.offset + u.numel]) for u in st.units if u.group is None]
         for u in st.units:
@@ -533,6 +599,14 @@ class TrainStep:
             if key in self._wT:                                   # only weights that a dgrad GEMM actually reads
                 tw = self._tW[:n * k].view(k, n)
                 plan += [T.transpose_pad(rm, tw, n, run=False), T.pack(tw, self._wT[key], run=False)]
+        if self.lora is not None:
+            for ad in self.lora.adapters:
+                for rm, pk in ((ad.A, ad.A_p), (ad.B, ad.B_p)):
+                    plan.append(T.pack(rm, pk, run=False))
+                    if pk.data_ptr() in self._wT:
+                        n, k = rm.shape
+                        tw = self._tW[:n * k].view(k, n)
+                        plan += [T.transpose_pad(rm, tw, n, run=False), T.pack(tw, self._wT[pk.data_ptr()], run=False)]
         return plan
 
     # ---- running ------------------------------------------------------------------------------------------------
@@ -607,8 +681,9 @@ class TrainStep:
         for upto, key in self._ready:
             ops.run_all(self.backward_ops[done:upto])
             done = upto
-            if key in by_key:
-                reduce(by_key[key])
+            b = by_key.get(key) or by_key.get("lora." + key)
+            if b is not None:
+                reduce(b)
         ops.run_all(self.backward_ops[done:])
         for i in comm_order(lay.buckets):                          # whatever has no marker (plain tensors) goes last
             if lay.buckets[i].key not in reduced:

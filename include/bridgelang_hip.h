@@ -221,6 +221,11 @@ int bl_scale_residual_bf16(const bl_bf16* u, int64_t ldu, const bl_bf16* scale, 
 int bl_layerscale_backward_bf16(const bl_bf16* dy, int64_t lddy, const bl_bf16* u, int64_t ldu, const bl_bf16* scale,
                                 bl_bf16* du, int64_t lddu, float* dscale, float* partial_ws, int64_t partial_ws_floats,
                                 int32_t rows, int32_t cols, void* stream);
+/* LoRA (vla-scripts/finetune.py:174-189): out = bf16(s * x) for the small rank-space tensors; gradient mask that keeps
+ * the off-block entries of a fused adapter's B [n_rows, members * rp] at zero (row n belongs to member n / (n_rows /
+ * members), or n % members when the members' rows are interleaved). */
+int bl_scale_bf16(const bl_bf16* x, float s, bl_bf16* out, int64_t n, void* stream);
+int bl_lora_block_mask_f32(float* g, int32_t n_rows, int32_t R, int32_t rp, int32_t members, int32_t interleave, void* stream);
 /* Device memset / device-to-device copy on `stream` (replayable steps of the training plans). */
 int bl_memset_zero(void* dst, int64_t bytes, void* stream);
 int bl_copy_bytes(void* dst, const void* src, int64_t bytes, void* stream);

@@ -1,0 +1,121 @@
+"""LoRA fine-tuning step (vla-scripts/finetune.py:174-189,253-318) vs autograd over the CPU oracle: adapters on every
+nn.Linear except lm_head (vision qkv/proj/fc1/fc2, projector, q/k/v/o/gate/up/down), scaling alpha/r = 16/32, base frozen,
+AdamW(lr, weight_decay=0.01 — torch default) on the adapters only."""
+import pytest
+import torch
+
+from oracle import restate as R
+from test_train_step_gpu import cos, make_batch, oracle_loss
+
+pytestmark = pytest.mark.gpu
+
+
+def random_adapters(lora, seed, b_std=0.02):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for ad in lora.adapters:
+        for j, mod in enumerate(ad.modules):
+            out, inp = ad.shapes[j]
+            sd[f"base_model.model.{mod}.lora_A.weight"] = (torch.randn(lora.r, inp, generator=g) / lora.r).to(torch.bfloat16).float()
+            sd[f"base_model.model.{mod}.lora_B.weight"] = (torch.randn(out, lora.r, generator=g) * b_std).to(torch.bfloat16).float()
+    return sd
+
+
+def effective_sd(sd, ad_sd, scaling, mods):
+    """HF-named weights with W + s·B·A substituted (differentiable w.r.t. the adapter tensors)."""
+    out = dict(sd)
+    for mod in mods:
+        a, b = ad_sd[f"base_model.model.{mod}.lora_A.weight"], ad_sd[f"base_model.model.{mod}.lora_B.weight"]
+        out[mod + ".weight"] = sd[mod + ".weight"] + scaling * (b @ a)
+    return out
+
+
+def test_lora_structure_and_names(dev):
+    from bridgelang_amd.training.lora import LoraAdapters
+    from bridgelang_amd.weights import allocate, tiny_dims, openvla_7b_dims
+    dims = tiny_dims()
+    w = allocate(dims, dev).fill_synthetic(seed=3)
+    lora = LoraAdapters(w, r=32)
+    assert lora.scaling == 0.5
+    mods = [m for ad in lora.adapters for m in ad.modules]
+    assert "language_model.lm_head" not in mods and not any("patch_embed" in m for m in mods)
+    per_layer = ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"]
+    assert all(f"language_model.model.layers.0.{n}" in mods for n in per_layer)
+    assert all(f"projector.fc{i}" in mods for i in (1, 2, 3))
+    assert "vision_backbone.featurizer.blocks.0.attn.qkv" in mods and "vision_backbone.fused_featurizer.blocks.1.mlp.fc2" in mods
+    sd = lora.state_dict()
+    assert sd["base_model.model.language_model.model.layers.1.mlp.up_proj.lora_A.weight"].shape == (32, dims.llm_dim)
+    assert sd["base_model.model.language_model.model.layers.1.mlp.up_proj.lora_B.weight"].shape == (dims.llm_inter, 32)
+    assert all(v.abs().sum() == 0 for k, v in sd.items() if "lora_B" in k)            # gaussian init: B = 0
+    a = sd["base_model.model.projector.fc2.lora_A.weight"]
+    assert abs(a.std().item() - 1 / 32) < 0.1 / 32
+    rt = LoraAdapters(w, r=32, seed=1).load_state_dict(sd).state_dict()               # round trip through the fused layout
+    assert all(torch.equal(rt[k], sd[k]) for k in sd)
+    # 7B parameter count of the adapters on the executed path (LLM 32 layers + projector + 23 + 26 vision blocks)
+    d7 = openvla_7b_dims()
+    r = 32
+    llm = 32 * (4 * r * 2 * 4096 + 3 * r * (4096 + 11008))
+    proj = r * ((2176 + 8704) + (8704 + 4096) + (4096 + 4096))
+    dino = d7.dino.n_run * r * ((1024 + 3072) + 2048 + 2 * (1024 + 4096))
+    sig = d7.siglip.n_run * r * ((1152 + 3456) + 2304 + 2 * (1152 + 4304))
+    assert llm == 79_953_920 and llm + proj + dino + sig == 107_862_016
+
+
+def test_lora_gradients_and_adamw_step(dev):
+    from bridgelang_amd.training.lora import LoraAdapters
+    from bridgelang_amd.training.step import TrainStep
+    from bridgelang_amd.weights import allocate, tiny_dims
+    dims = tiny_dims()
+    w = allocate(dims, dev).fill_synthetic(seed=3)
+    sd = {k: v.float().cpu() for k, v in w.state_dict().items()}
+    lora = LoraAdapters(w, r=32)
+    ad_sd = random_adapters(lora, seed=7)
+    lora.load_state_dict(ad_sd)
+    mods = [m for ad in lora.adapters for m in ad.modules]
+    B, L, lr = 3, 20, 5e-4
+    ts = TrainStep(w, "lora", B, L, lora=lora, max_grad_norm=float("inf"), weight_decay=0.01)
+    assert ts.store.n_params == sum(ad.A.numel() + ad.B.numel() for ad in lora.adapters)
+    ids, mask, labels, pv = make_batch(dims, B, L)
+    ts.set_batch(ids, mask, pv, labels)
+    loss = ts.forward().item()
+    ts.backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in ad_sd.items()}
+    ref = oracle_loss(effective_sd(sd, params, lora.scaling, mods), dims, ids, mask, labels, pv)
+    ref.backward()
+    print(f"[lora] loss {loss:.5f} vs oracle {ref.item():.5f}; {len(params)} adapter tensors, {lora.n_params()} params")
+    assert abs(loss - ref.item()) <= 3e-3 * abs(ref.item())
+    masters = {u.key: ts.store.grad[u.offset:u.offset + u.numel] for u in ts.store.units}
+    got = lora.state_dict(masters)                      # gradients, un-fused into PEFT names / shapes
+    worst = 1.0
+    for k, want in params.items():
+        g, scale = got[k], want.grad.abs().max().item()
+        c = cos(g, want.grad)
+        worst = min(worst, c)
+        assert scale > 0 and c > 0.985 and (g - want.grad).abs().max().item() <= 0.08 * scale, (k, c)
+    print(f"[lora] worst adapter-gradient cosine {worst:.5f}")
+    # off-block entries of the fused adapters carry no gradient
+    for i, ad in enumerate(lora.adapters):
+        if len(ad.modules) > 1:
+            gB = masters[f"lora.{i}.B"].view(ad.B.shape).cpu()
+            keep = torch.zeros_like(gB, dtype=torch.bool)
+            for j in range(len(ad.modules)):
+                keep[ad.member_rows(j), j * 64:(j + 1) * 64] = True
+            assert (gB[~keep] == 0).all() and gB[keep].abs().sum() > 0
+    # one AdamW step (no clipping in finetune.py; torch default weight decay on every adapter tensor)
+    opt = torch.optim.AdamW(list(params.values()), lr=lr)
+    opt.step()
+    ts.clip_grad_norm()
+    ts.optimizer_step(lr)
+    full = ts.store.full_master()
+    new = lora.state_dict({u.key: full[u.offset:u.offset + u.numel] for u in ts.store.units})
+    live = lora.state_dict()
+    for k, want in params.items():
+        upd, upd_ref = new[k] - ad_sd[k], want.detach() - ad_sd[k]
+        assert cos(upd, upd_ref) > 0.97, (k, cos(upd, upd_ref))
+        assert torch.equal(live[k], new[k].to(torch.bfloat16).float()), k
+    # second forward runs on the re-packed adapters: loss must move the way the oracle's does
+    loss2 = ts.forward().item()
+    ref2 = oracle_loss(effective_sd(sd, {k: v.detach().to(torch.bfloat16).float() for k, v in params.items()}, lora.scaling, mods),
+                       dims, ids, mask, labels, pv)
+    print(f"[lora] after one step: loss {loss2:.5f} vs oracle {ref2.item():.5f}")
+    assert abs(loss2 - ref2.item()) <= 3e-3 * abs(ref2.item()) and loss2 < loss
