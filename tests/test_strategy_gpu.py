@@ -78,3 +78,40 @@ def test_run_vla_training_overfits_and_checkpoints(dev, tmp_path):
     # schedules
     assert lr_at(0, 1.0, "linear-warmup+cosine-decay", 100, 10) == 0.0 and lr_at(10, 1.0, "linear-warmup+cosine-decay", 100, 10) == 1.0
     assert abs(lr_at(55, 1.0, "linear-warmup+cosine-decay", 100, 10) - 0.5) < 1e-9
+
+
+def test_lora_finetune_loop(dev, tmp_path):
+    """finetune.py loop: LoRA adapters over DummyDataset batches; loss falls, adapter + merged checkpoints load back."""
+    from safetensors.torch import load_file
+    from bridgelang_amd import weights as W
+    from bridgelang_amd.extern.hf.configuration_prismatic import OpenVLAConfig
+    from bridgelang_amd.extern.hf.modeling_prismatic import OpenVLAForActionPrediction
+    from bridgelang_amd.extern.hf.processing_prismatic import PrismaticImageProcessor
+    from bridgelang_amd.training.finetune import FinetuneConfig, finetune
+    from bridgelang_amd.util.data_utils import PaddedCollatorForActionPrediction
+    from bridgelang_amd.vla.action_tokenizer import ActionTokenizer
+    from bridgelang_amd.vla.datasets import DummyDataset
+    dims = W.tiny_dims()
+    vlm = OpenVLAForActionPrediction(OpenVLAConfig(norm_stats={}), device=dev, dims=dims).init_synthetic(seed=1)
+    base = {k: v.float().cpu() for k, v in vlm.state_dict().items()}
+    tok = WordTokenizer()
+    at = ActionTokenizer(tok)
+    ds = DummyDataset(at, tok, PrismaticImageProcessor().apply_transform, length=64, seed=0)
+    B, steps = 4, 10
+    loader = torch.utils.data.DataLoader(Repeat(ds, 4, steps, B), batch_size=B,
+                                         collate_fn=PaddedCollatorForActionPrediction(2048, tok.pad_token_id, padding_side="right"))
+    cfg = FinetuneConfig(run_root_dir=tmp_path / "run", adapter_tmp_dir=tmp_path / "adapter", batch_size=B, max_steps=steps,
+                         learning_rate=2e-3, log_every=1)
+    out = finetune(vlm, loader, at, cfg, log_path=tmp_path / "log.jsonl")
+    rows = [json.loads(l) for l in open(tmp_path / "log.jsonl")]
+    print("lora losses", [round(r["train_loss"], 3) for r in rows])
+    assert out["steps"] == steps and rows[-1]["train_loss"] < 0.8 * rows[0]["train_loss"]
+    ad = load_file(out["adapter"])
+    assert "base_model.model.language_model.model.layers.0.self_attn.q_proj.lora_B.weight" in ad
+    assert any(v.abs().sum() > 0 for k, v in ad.items() if "lora_B" in k)
+    merged = load_file(out["model"])
+    assert set(merged) == set(base)
+    k = "language_model.model.layers.0.self_attn.q_proj.weight"
+    assert not torch.equal(merged[k].float(), base[k])                        # adapters merged in
+    assert torch.equal(merged["language_model.lm_head.weight"].float(), base["language_model.lm_head.weight"])
+    assert all(torch.equal(vlm.state_dict()[n].float().cpu(), base[n]) for n in (k, "projector.fc1.weight"))   # base frozen
