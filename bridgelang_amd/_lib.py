@@ -86,6 +86,7 @@ SIGNATURES = {
     "bl_gelu_backward_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "bl_rope_backward_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "bl_transpose_pad_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "bl_transpose_pack_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "bl_sumsq_partial_f32": (C.c_int, [_vp, _i64, _vp, _i32, _vp]),
     "bl_clip_coef_f32": (C.c_int, [_vp, _i32, _f32, _vp, _vp]),
     "bl_adamw_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),

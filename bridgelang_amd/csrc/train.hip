@@ -376,6 +376,57 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const uint16_t* in, 
   }
 }
 
+// Fast path (cols % 64 == 0): 256 × 64 tile through LDS, 16-byte global loads, transposing LDS reads
+// (ds_read_b64_tr_b16: a 16-lane group reads a 4-row × 16-column block and each lane receives its column's 4 values),
+// 16-byte stores. LDS rows are 128 B; 32-byte chunk PAIRS are swizzled pair' = pair ^ g(row) so the 8 rows one
+// half-wave touches per transposing read fall on disjoint banks. PACKED writes the fragment-major layout of
+// bl_pack_weight_bf16 for the [cols, rows_pad] matrix directly (the "B" operand of the wgrad GEMM) — one pass instead of
+// transpose + pack.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ int tr_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void transpose_fast_kernel(const uint16_t* in, long ldi, int rows, int cols,
+                                                             uint16_t* out, long ldo, int rows_pad) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(16))) char tile[256 * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int r0 = blockIdx.x * 256, c0 = blockIdx.y * 64;
+  u32x4_t v[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int piece = tid + 256 * u, row = piece >> 3, ch = piece & 7;
+    v[u] = (u32x4_t){0u, 0u, 0u, 0u};
+    if (r0 + row < rows) v[u] = *(const u32x4_t*)(in + (long)(r0 + row) * ldi + c0 + ch * 8);
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int piece = tid + 256 * u, row = piece >> 3, ch = piece & 7;
+    *(u32x4_t*)(tile + row * 128 + (((((ch >> 1) ^ tr_swz(row)) << 1) | (ch & 1)) << 4)) = v[u];
+  }
+  __syncthreads();
+  const int col = c0 + 16 * wave + l15;
+#pragma unroll
+  for (int tb = 0; tb < 8; ++tb) {
+    if (r0 + tb * 32 >= rows_pad) break;
+    u32x2_t w[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = tb * 32 + 8 * lg + 4 * i + (l15 >> 2);
+      const char* ap = tile + row * 128 + ((((wave ^ tr_swz(row)) << 1) | ((l15 & 3) >> 1)) << 4) + (l15 & 1) * 8;
+      w[i] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)ap));
+    }
+    const u32x4_t o = {w[0][0], w[0][1], w[1][0], w[1][1]};      // 8 consecutive rows t = r0 + 32 tb + 8 lg + j of column `col`
+    if (PACKED) {
+      const long unit = ((long)(c0 / 16 + wave) * (rows_pad / 32) + (r0 / 32 + tb)) * 64 + lane;
+      *(u32x4_t*)(out + unit * 8) = o;
+    } else {
+      *(u32x4_t*)(out + (long)col * ldo + r0 + tb * 32 + 8 * lg) = o;
+    }
+  }
+#endif
+}
+
 // ---- optimizer ----
 // sum of squares of an fp32 tensor → per-block partials (grad-norm)
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, long n, float* partial) {
@@ -643,8 +694,23 @@ extern "C" int bl_transpose_pad_bf16(const bl_bf16* in, int64_t ldi, int32_t row
                                      int64_t ldo, int32_t rows_pad, void* stream) {
   if (!in || !out) return BL_E_ARG;
   if (rows <= 0 || cols <= 0 || rows_pad < rows || ldo < rows_pad) return BL_E_SHAPE;
-  hipLaunchKernelGGL(transpose_pad_kernel, dim3((rows_pad + 63) / 64, (cols + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                     in, (long)ldi, rows, cols, out, (long)ldo, rows_pad);
+  if ((cols % 64) == 0 && (rows_pad % 32) == 0 && (ldi % 8) == 0 && (ldo % 8) == 0 && bl_aligned16(in) && bl_aligned16(out))
+    hipLaunchKernelGGL((transpose_fast_kernel<false>), dim3((rows_pad + 255) / 256, cols / 64), dim3(256), 0,
+                       (hipStream_t)stream, in, (long)ldi, rows, cols, out, (long)ldo, rows_pad);
+  else
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((rows_pad + 63) / 64, (cols + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       in, (long)ldi, rows, cols, out, (long)ldo, rows_pad);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_transpose_pack_bf16(const bl_bf16* in, int64_t ldi, int32_t rows, int32_t cols, bl_bf16* out_packed,
+                                      int32_t rows_pad, void* stream) {
+  if (!in || !out_packed) return BL_E_ARG;
+  if (rows <= 0 || cols <= 0 || rows_pad < rows || (cols % 64) || (rows_pad % 32) || (ldi % 8)) return BL_E_SHAPE;
+  if (!bl_aligned16(in) || !bl_aligned16(out_packed)) return BL_E_ALIGN;
+  hipLaunchKernelGGL((transpose_fast_kernel<true>), dim3((rows_pad + 255) / 256, cols / 64), dim3(256), 0,
+                     (hipStream_t)stream, in, (long)ldi, rows, cols, out_packed, 0L, rows_pad);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

@@ -197,3 +197,11 @@ def lora_block_mask(g: torch.Tensor, rp: int, members: int, interleave: bool, ru
     n, R = g.shape
     assert g.is_contiguous()
     return _op("bl_lora_block_mask_f32", (_f32(g, "g").data_ptr(), n, R, rp, members, int(interleave)), (g,), run)
+
+
+def transpose_pack(a: torch.Tensor, out_packed: torch.Tensor, rows_pad: int, run: bool = True) -> Op:
+    """[rows, cols] → packed [cols/16, rows_pad/32, 64, 8] (the transposed matrix in fragment-major layout)."""
+    rows, cols = a.shape
+    assert out_packed.numel() == cols * rows_pad and out_packed.is_contiguous()
+    return _op("bl_transpose_pack_bf16", (_bf16(a, "a").data_ptr(), _rows(a, "a"), rows, cols, _bf16(out_packed, "out").data_ptr(),
+                                          rows_pad), (a, out_packed), run, nbytes=2.0 * cols * (rows + rows_pad))

@@ -321,8 +321,11 @@ class TrainStep:
         tA = self.tA[:N * Tp].view(N, Tp)
         tB = self.tB[:K * Tp].view(K, Tp)
         tBp = self.tBp[:K * Tp].view(K // 16, Tp // 32, 64, 8)
-        return [T.transpose_pad(dy, tA, Tp, run=False), T.transpose_pad(x, tB, Tp, run=False),
-                T.pack(tB, tBp, run=False), ops.gemm(tA, tBp, gview, EPI_F32, algo_nk=(K, Tn), run=False)]
+        if K % 64 == 0:                        # one pass: transpose straight into the packed operand layout
+            prep = [T.transpose_pack(x, tBp, Tp, run=False)]
+        else:
+            prep = [T.transpose_pad(x, tB, Tp, run=False), T.pack(tB, tBp, run=False)]
+        return [T.transpose_pad(dy, tA, Tp, run=False)] + prep + [ops.gemm(tA, tBp, gview, EPI_F32, algo_nk=(K, Tn), run=False)]
 
     def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, packed: torch.Tensor) -> List[Op]:
         """Weight gradient of a base linear; [] when the weight is frozen."""
@@ -597,16 +600,14 @@ class TrainStep:
             plan.append(T.pack(rm, u.group.packed, run=False))
             key = u.group.packed.data_ptr()
             if key in self._wT:                                   # only weights that a dgrad GEMM actually reads
-                tw = self._tW[:n * k].view(k, n)
-                plan += [T.transpose_pad(rm, tw, n, run=False), T.pack(tw, self._wT[key], run=False)]
+                plan.append(T.transpose_pack(rm, self._wT[key], n, run=False))
         if self.lora is not None:
             for ad in self.lora.adapters:
                 for rm, pk in ((ad.A, ad.A_p), (ad.B, ad.B_p)):
                     plan.append(T.pack(rm, pk, run=False))
                     if pk.data_ptr() in self._wT:
                         n, k = rm.shape
-                        tw = self._tW[:n * k].view(k, n)
-                        plan += [T.transpose_pad(rm, tw, n, run=False), T.pack(tw, self._wT[pk.data_ptr()], run=False)]
+                        plan.append(T.transpose_pack(rm, self._wT[pk.data_ptr()], n, run=False))
         return plan
 
     # ---- running ------------------------------------------------------------------------------------------------

@@ -205,6 +205,10 @@ int bl_rope_backward_bf16(bl_bf16* dqkv, int32_t B, int32_t S, int32_t H, int32_
 /* out[c][r] = in[r][c], rows padded with zeros to rows_pad (the reduction dim of a wgrad GEMM must be a multiple of 64). */
 int bl_transpose_pad_bf16(const bl_bf16* in, int64_t ldi, int32_t rows, int32_t cols, bl_bf16* out, int64_t ldo,
                           int32_t rows_pad, void* stream);
+/* Same transpose written straight into the fragment-major packed layout of bl_pack_weight_bf16 for the [cols, rows_pad]
+ * matrix (cols % 64 == 0, rows_pad % 32 == 0): the packed operand of a wgrad GEMM in one pass. */
+int bl_transpose_pack_bf16(const bl_bf16* in, int64_t ld_in, int32_t rows, int32_t cols, bl_bf16* out_packed,
+                           int32_t rows_pad, void* stream);
 /* Global gradient norm (fsdp.py:268-270): per-tensor partial sums of squares, then norm and clip coefficient
  * out_norm_coef = {||g||, min(1, max_norm / (||g|| + 1e-6))} (torch.nn.utils.clip_grad_norm_). */
 int bl_sumsq_partial_f32(const float* g, int64_t n, float* partial, int32_t nblocks, void* stream);

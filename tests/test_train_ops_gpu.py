@@ -238,3 +238,21 @@ def test_layernorm_and_layerscale_backward(dev, rows, dim):
     T.layerscale_backward(dv(dy, dev), dv(u, dev), dv(ls, dev), du, dls, torch.empty(((rows + 63) // 64) * dim, device=dev))
     grad_close(du, ur.grad, "layerscale du")
     grad_close(dls, lr_.grad, "layerscale dscale")
+
+
+@pytest.mark.parametrize("rows,cols", [(300, 192), (4608, 4096), (37, 64), (1000, 1088)])
+def test_fast_transpose_and_transpose_pack(dev, rows, cols):
+    from bridgelang_amd import ops, train_ops as T
+    a = rand_bf16((rows, cols), rows + cols)
+    rp = (rows + 63) // 64 * 64
+    A = dv(a, dev)
+    t = torch.full((cols, rp), 7.0, dtype=torch.bfloat16, device=dev)
+    T.transpose_pad(A, t, rp)
+    assert torch.equal(t.cpu().float()[:, :rows], a.t()) and (t.cpu()[:, rows:] == 0).all()
+    pk = torch.full((cols // 16, rp // 32, 64, 8), 7.0, dtype=torch.bfloat16, device=dev)
+    T.transpose_pack(A, pk, rp)
+    assert torch.equal(pk, ops.pack_weight(t))
+    sub = A[:, 64:128] if cols >= 128 else A                  # strided source view
+    t2 = torch.empty(sub.shape[1], rp, dtype=torch.bfloat16, device=dev)
+    T.transpose_pad(sub, t2, rp)
+    assert torch.equal(t2.cpu().float()[:, :rows], sub.cpu().float().t())
