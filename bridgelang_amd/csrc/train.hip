@@ -717,7 +717,7 @@ extern "C" int bl_transpose_pack_bf16(const bl_bf16* in, int64_t ldi, int32_t ro
 
 extern "C" int bl_sumsq_partial_f32(const float* g, int64_t n, float* partial, int32_t nblocks, void* stream) {
   if (!g || !partial) return BL_E_ARG;
-  if (n <= 0 || nblocks <= 0 || nblocks > 1024) return BL_E_SHAPE;
+  if (n <= 0 || nblocks <= 0 || nblocks > 8192) return BL_E_SHAPE;
   hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, g, (long)n, partial);
   BL_CHECK_LAUNCH();
   return BL_OK;

@@ -157,7 +157,7 @@ class ParamStore:
             lo_l = lay.local_offset(b)
             self.master[lo_l:lo_l + hi - lo].copy_(full[lo - b.offset:hi - b.offset])
             del full
-        self.blocks_per_bucket = 256
+        self.blocks_per_bucket = 2048
         self.partial = torch.zeros(self.blocks_per_bucket * max(len(lay.buckets), 1), dtype=torch.float32, device=dev)
         self.norm_coef = torch.zeros(2, dtype=torch.float32, device=dev)     # [total norm, clip coefficient]
         self.step_count = 0
@@ -287,6 +287,7 @@ class TrainStep:
         self.vis = [self._alloc_tower(tw) for tw in towers]
         # ---- transposed weights for dgrad ----
         self._wT: Dict[int, torch.Tensor] = {}
+        self.ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
         self.vision_forward_ops: List[Op] = []
         for tw, sv, col in zip(towers, self.vis, (0, d.dino.dim)):
             self.vision_forward_ops += self._plan_tower_forward(tw, col, sv)
@@ -300,6 +301,11 @@ class TrainStep:
         self._comm_stream = torch.cuda.Stream(device=dev) if self.comm.active else None
 
     # ---- helpers ------------------------------------------------------------------------------------------------
+    def _g(self, *a, **k) -> Op:
+        """Prepared GEMM with the split-K scratch: training has no batch-slot invariance to keep (engine.py keeps it
+        off for inference), so ragged last rounds of K >= 8192 GEMMs are split along K."""
+        return ops.gemm(*a, workspace=self.ws, run=False, **k)
+
     def wT(self, packed: torch.Tensor) -> torch.Tensor:
         """[K, N]-packed transposed copy of a packed [N, K] weight (built on first use, refreshed by repack)."""
         key = packed.data_ptr()
@@ -309,7 +315,7 @@ class TrainStep:
         return self._wT[key]
 
     def _dgrad(self, dy: torch.Tensor, packed: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, **kw) -> Op:
-        return ops.gemm(dy, self.wT(packed), out, epilogue, run=False, **kw)
+        return self._g(dy, self.wT(packed), out, epilogue, **kw)
 
     def _wgrad_into(self, dy: torch.Tensor, x: torch.Tensor, gview: torch.Tensor) -> List[Op]:
         """gview[N, K] (fp32) = dyᵀ[N, T] · x[T, K] as the NT GEMM over token-padded transposes."""
@@ -325,7 +331,7 @@ class TrainStep:
             prep = [T.transpose_pack(x, tBp, Tp, run=False)]
         else:
             prep = [T.transpose_pad(x, tB, Tp, run=False), T.pack(tB, tBp, run=False)]
-        return [T.transpose_pad(dy, tA, Tp, run=False)] + prep + [ops.gemm(tA, tBp, gview, EPI_F32, algo_nk=(K, Tn), run=False)]
+        return [T.transpose_pad(dy, tA, Tp, run=False)] + prep + [self._g(tA, tBp, gview, EPI_F32, algo_nk=(K, Tn))]
 
     def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, packed: torch.Tensor) -> List[Op]:
         """Weight gradient of a base linear; [] when the weight is frozen."""
@@ -334,14 +340,14 @@ class TrainStep:
 
     def _lin(self, x: torch.Tensor, packed: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, **kw) -> List[Op]:
         """Forward of one nn.Linear: the base GEMM, plus the LoRA branch y += s·(x Aᵀ) Bᵀ when it carries an adapter."""
-        plan = [ops.gemm(x, packed, out, epilogue, run=False, **kw)]
+        plan = [self._g(x, packed, out, epilogue, **kw)]
         ad = self.lora.get(packed) if self.lora is not None else None
         if ad is not None:
             assert "out_map" not in kw, "row-mapped outputs carry no adapter"
             t = torch.zeros(x.shape[0], ad.R, dtype=torch.bfloat16, device=self.device)
             self._lora_t[packed.data_ptr()] = t
             n = ad.group.n
-            plan += [ops.gemm(x, ad.A_p, t, EPI_NONE, run=False),
+            plan += [self._g(x, ad.A_p, t, EPI_NONE),
                      ops.gemm(t, ad.B_p, out, ops.EPI_BIAS_RES, bias=self.lora.zero_vec[:n], scale=self.lora.scale_vec[:n],
                               res=out, run=False)]
         return plan
@@ -384,7 +390,7 @@ class TrainStep:
     def _plan_forward(self) -> List[Op]:
         d, w, B, S = self.dims, self.w, self.B, self.S
         D, H, hd = d.llm_dim, d.llm_heads, d.head_dim
-        g = lambda *a, **k: ops.gemm(*a, run=False, **k)
+        g = self._g
         plan: List[Op] = []
         # projector with the pre-activations kept (modeling_prismatic.py:151-156)
         lin = self._lin
@@ -484,7 +490,7 @@ class TrainStep:
         t, B, eps = tw.dims, self.B, self.dims.ln_eps
         Tk, Dm, hd = t.tokens, t.dim, t.head_dim
         col = self._vis.vbuf[1 if feat_col else 0]["col"]          # one im2col buffer per tower (kept for the patch wgrad)
-        g = lambda *a, **k: ops.gemm(*a, run=False, **k)
+        g = self._g
         x0 = sv["x"][0]
         plan = [ops.im2col_patch14(self.pixel_values, t.chan0, col, run=False)]
         if tw.prefix is not None:
