@@ -93,6 +93,7 @@ SIGNATURES = {
     "bl_rope_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "bl_scale_residual_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "bl_layerscale_backward_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "bl_gemm_tn_small_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _i32, _vp, _i64, _vp]),
     "bl_scale_bf16": (C.c_int, [_vp, _f32, _vp, _i64, _vp]),
     "bl_lora_block_mask_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "bl_memset_zero": (C.c_int, [_vp, _i64, _vp]),

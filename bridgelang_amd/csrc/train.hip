@@ -427,6 +427,98 @@ __global__ __launch_bounds__(256) void transpose_fast_kernel(const uint16_t* in,
 #endif
 }
 
+// ---- small-output TN GEMM:  C = Pᵀ·Q  with P [T, R] (R ∈ {64, 128, 192}: a LoRA rank block) and Q [T, N] (N % 64 == 0),
+//      reduction over the rows — the adapter gradients dA = dtᵀ·x and dB = (tsᵀ·dy)ᵀ read dy / x exactly once, untransposed.
+// HBM-bound on Q. Workgroup = 4 waves = one 64-column slab of Q (× an optional slice of T: partials to a workspace,
+// summed by reduce_partials_kernel — deterministic, no atomics). Per 32-row step both slabs are staged row-major in LDS
+// (double buffered) and turned into MFMA operands by transposing reads; wave w owns 16 of the 64 columns and all R rows.
+// TRANS = false: C[R][N] (lane owns 4 consecutive n);  TRANS = true: C[N][R] (lane owns 4 consecutive r).
+__device__ __forceinline__ int tr_swz8(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <int R, bool TRANS>
+__global__ __launch_bounds__(256) void gemm_tn_small_kernel(const uint16_t* P, long ldp, const uint16_t* Q, long ldq, int T,
+                                                            int N, float* C, long ldc, int t_per_split, long split_stride) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int RB = R / 16, PROW = R * 2, PCH = R / 8;          // P tile: 32 rows × PROW bytes, PCH 16-byte chunks per row
+  constexpr int PLD = (32 * PCH + 255) / 256;                    // 16-byte P loads per thread per step
+  __shared__ __attribute__((aligned(16))) char q_lds[2][32 * 128];
+  __shared__ __attribute__((aligned(16))) char p_lds[2][32 * PROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int n0 = blockIdx.x * 64;
+  const int t_begin = blockIdx.y * t_per_split, t_end = min(T, t_begin + t_per_split);
+  float* Cs = C + (long)blockIdx.y * split_stride;
+  f32x4_t acc[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  auto pswz = [](int row) { return (PROW == 256) ? tr_swz8(row) : tr_swz(row); };
+  u32x4_t qreg, preg[PLD];
+  auto load = [&](int t0) {
+    const int row = tid >> 3, ch = tid & 7;
+    qreg = (u32x4_t){0u, 0u, 0u, 0u};
+    if (t0 + row < t_end) qreg = *(const u32x4_t*)(Q + (long)(t0 + row) * ldq + n0 + ch * 8);
+#pragma unroll
+    for (int u = 0; u < PLD; ++u) {
+      const int piece = tid + 256 * u, prow = piece / PCH, pch = piece - prow * PCH;
+      preg[u] = (u32x4_t){0u, 0u, 0u, 0u};
+      if (piece < 32 * PCH && t0 + prow < t_end) preg[u] = *(const u32x4_t*)(P + (long)(t0 + prow) * ldp + pch * 8);
+    }
+  };
+  auto stage = [&](int buf) {
+    const int row = tid >> 3, ch = tid & 7;
+    *(u32x4_t*)(q_lds[buf] + row * 128 + (((((ch >> 1) ^ tr_swz(row)) << 1) | (ch & 1)) << 4)) = qreg;
+#pragma unroll
+    for (int u = 0; u < PLD; ++u) {
+      const int piece = tid + 256 * u, prow = piece / PCH, pch = piece - prow * PCH;
+      if (piece < 32 * PCH)
+        *(u32x4_t*)(p_lds[buf] + prow * PROW + (((((pch >> 1) ^ pswz(prow)) << 1) | (pch & 1)) << 4)) = preg[u];
+    }
+  };
+  // transposing fragment: 8 consecutive rows (8·lg + j) of column block `cb` (16 columns) of a staged tile
+  auto frag = [&](const char* tile, int rowbytes, int cb, bool p_tile) -> bf16x8_t {
+    u32x2_t w[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = 8 * lg + 4 * i + (l15 >> 2);
+      const int sw = p_tile ? pswz(row) : tr_swz(row);
+      const char* ap = tile + row * rowbytes + ((((cb ^ sw) << 1) | ((l15 & 3) >> 1)) << 4) + (l15 & 1) * 8;
+      w[i] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)ap));
+    }
+    const u32x4_t o = {w[0][0], w[0][1], w[1][0], w[1][1]};
+    return __builtin_bit_cast(bf16x8_t, o);
+  };
+
+  int buf = 0;
+  if (t_begin < t_end) {
+    load(t_begin);
+    stage(0);
+  }
+  __syncthreads();
+  for (int t0 = t_begin; t0 < t_end; t0 += 32) {
+    const bool more = t0 + 32 < t_end;
+    if (more) load(t0 + 32);                                   // global loads of the next step fly under this step's MFMAs
+    const bf16x8_t qf = frag(q_lds[buf], 128, wave, false);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const bf16x8_t pf = frag(p_lds[buf], PROW, rb, true);
+      acc[rb] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf, acc[rb], 0, 0, 0)
+                      : __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, pf, acc[rb], 0, 0, 0);
+    }
+    if (more) stage(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    if (TRANS) {   // acc: rows r = 16 rb + 4 lg + reg, column n = n0 + 16 wave + l15  →  C[n][r..r+3]
+      *(f32x4_t*)(Cs + (long)(n0 + 16 * wave + l15) * ldc + rb * 16 + lg * 4) = acc[rb];
+    } else {       // acc: rows n = n0 + 16 wave + 4 lg + reg, column r = 16 rb + l15   →  C[r][n..n+3]
+      *(f32x4_t*)(Cs + (long)(rb * 16 + l15) * ldc + n0 + 16 * wave + lg * 4) = acc[rb];
+    }
+  }
+#endif
+}
+
 // ---- optimizer ----
 // sum of squares of an fp32 tensor → per-block partials (grad-norm)
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, long n, float* partial) {
@@ -711,6 +803,39 @@ extern "C" int bl_transpose_pack_bf16(const bl_bf16* in, int64_t ldi, int32_t ro
   if (!bl_aligned16(in) || !bl_aligned16(out_packed)) return BL_E_ALIGN;
   hipLaunchKernelGGL((transpose_fast_kernel<true>), dim3((rows_pad + 255) / 256, cols / 64), dim3(256), 0,
                      (hipStream_t)stream, in, (long)ldi, rows, cols, out_packed, 0L, rows_pad);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_gemm_tn_small_bf16(const bl_bf16* P, int64_t ldp, const bl_bf16* Q, int64_t ldq, int32_t T, int32_t R,
+                                     int32_t N, float* C, int64_t ldc, int32_t transpose_out, float* partial_ws,
+                                     int64_t partial_ws_floats, void* stream) {
+  if (!P || !Q || !C) return BL_E_ARG;
+  if (T <= 0 || (R != 64 && R != 128 && R != 192) || N <= 0 || (N % 64) || (ldp % 8) || (ldq % 8) || (ldc % 4)) return BL_E_SHAPE;
+  if (!bl_aligned16(P) || !bl_aligned16(Q) || !bl_aligned16(C)) return BL_E_ALIGN;
+  if (ldc != (transpose_out ? R : N)) return BL_E_SHAPE;          // dense output (the split partials mirror it)
+  // split T until the grid has ≥ 256 workgroups, when the caller provides room for the partials
+  const int slabs = N / 64;
+  int splits = 1;
+  while (slabs * splits < 256 && (T + splits * 2 - 1) / (splits * 2) >= 256 && partial_ws &&
+         (int64_t)splits * 2 * R * N <= partial_ws_floats)
+    splits *= 2;
+  const int t_per = ((T + splits - 1) / splits + 31) / 32 * 32;
+  float* out = splits > 1 ? partial_ws : C;
+  const long stride = (long)R * N;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(slabs, splits), block(256);
+#define BL_TN(RR)                                                                                                        \
+  case RR:                                                                                                               \
+    if (transpose_out) hipLaunchKernelGGL((gemm_tn_small_kernel<RR, true>), grid, block, 0, s, P, (long)ldp, Q, (long)ldq, T, N, \
+                                          out, (long)ldc, t_per, stride);                                                \
+    else hipLaunchKernelGGL((gemm_tn_small_kernel<RR, false>), grid, block, 0, s, P, (long)ldp, Q, (long)ldq, T, N, out, \
+                            (long)ldc, t_per, stride);                                                                   \
+    break;
+  switch (R) { BL_TN(64) BL_TN(128) BL_TN(192) }
+#undef BL_TN
+  if (splits > 1)
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)((stride + 63) / 64)), dim3(256), 0, s, partial_ws, splits, (int)stride, C);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

@@ -205,3 +205,15 @@ def transpose_pack(a: torch.Tensor, out_packed: torch.Tensor, rows_pad: int, run
     assert out_packed.numel() == cols * rows_pad and out_packed.is_contiguous()
     return _op("bl_transpose_pack_bf16", (_bf16(a, "a").data_ptr(), _rows(a, "a"), rows, cols, _bf16(out_packed, "out").data_ptr(),
                                           rows_pad), (a, out_packed), run, nbytes=2.0 * cols * (rows + rows_pad))
+
+
+def gemm_tn_small(P: torch.Tensor, Q: torch.Tensor, C: torch.Tensor, transpose_out: bool, ws: Optional[torch.Tensor] = None,
+                  run: bool = True) -> Op:
+    """C = Pᵀ·Q over the rows: P [T, R] (R in 64/128/192), Q [T, N]; C fp32 [R, N] or, transposed, [N, R]."""
+    Tn, R = P.shape
+    N = Q.shape[1]
+    assert Q.shape[0] == Tn and tuple(C.shape) == ((N, R) if transpose_out else (R, N)) and C.is_contiguous()
+    return _op("bl_gemm_tn_small_bf16",
+               (_bf16(P, "P").data_ptr(), _rows(P, "P"), _bf16(Q, "Q").data_ptr(), _rows(Q, "Q"), Tn, R, N, _f32(C, "C").data_ptr(),
+                C.shape[1], int(transpose_out), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0),
+               (P, Q, C, ws), run, flops=2.0 * Tn * R * N, nbytes=2.0 * Tn * (R + N) + 4.0 * R * N)

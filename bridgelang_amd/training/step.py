@@ -294,6 +294,7 @@ class TrainStep:
         self.forward_ops = self._plan_forward()
         tmax = max((t.numel() for t in self._lora_t.values()), default=8)
         self._lora_tmp, self._lora_tmp2 = z(tmax), z(tmax)
+        self.tn_ws = z(8 << 20, dtype=torch.float32) if lora is not None else None
         self._ready: List[Tuple[int, str]] = []      # (number of backward ops enqueued, bucket key complete at that point)
         self.backward_ops = self._plan_backward()
         self.repack_ops = self._plan_repack()
@@ -368,12 +369,13 @@ class TrainStep:
         dt = self._lora_tmp2[:t.numel()].view(t.shape)
         gB = st.grad_view(f"lora.{i}.B").view(ad.group.n, R)
         gA = st.grad_view(f"lora.{i}.A").view(R, ad.group.k)
+        # adapter gradients read dy / x once, untransposed (bl_gemm_tn_small_bf16): dB = (tsᵀ·dy)ᵀ, dA = dtᵀ·x
         plan.append(T.scale(t, s, ts, run=False))
-        plan += self._wgrad_into(dy, ts, gB)
+        plan.append(T.gemm_tn_small(ts, dy, gB, True, self.tn_ws, run=False))
         if len(ad.modules) > 1:
             plan.append(T.lora_block_mask(gB, R // len(ad.modules), len(ad.modules), ad.mode == "interleave", run=False))
         plan += [self._dgrad(dy, ad.B_p, dt), T.scale(dt, s, dt, run=False)]
-        plan += self._wgrad_into(dt, x, gA)
+        plan.append(T.gemm_tn_small(dt, x, gA, False, self.tn_ws, run=False))
         if dx is not None:
             plan.append(self._dgrad(dt, ad.A_p, dx, EPI_RES, res=dx))
         return plan

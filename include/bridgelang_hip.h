@@ -225,6 +225,13 @@ int bl_scale_residual_bf16(const bl_bf16* u, int64_t ldu, const bl_bf16* scale, 
 int bl_layerscale_backward_bf16(const bl_bf16* dy, int64_t lddy, const bl_bf16* u, int64_t ldu, const bl_bf16* scale,
                                 bl_bf16* du, int64_t lddu, float* dscale, float* partial_ws, int64_t partial_ws_floats,
                                 int32_t rows, int32_t cols, void* stream);
+/* Small-output TN GEMM for the LoRA adapter gradients (dA = dt^T x, dB = (ts^T dy)^T; finetune.py:174-189 → PEFT's
+ * autograd): C = P^T Q with P [T, R] (R = 64, 128 or 192), Q [T, N] (N % 64 == 0), both row-major bf16, reduction over
+ * the T rows, fp32 output — C [R, N] (transpose_out = 0) or C [N, R] (transpose_out = 1), dense (ldc = N or R). Reads Q
+ * once, untransposed. partial_ws (optional, fp32) lets small-N calls split T across workgroups deterministically. */
+int bl_gemm_tn_small_bf16(const bl_bf16* P, int64_t ldp, const bl_bf16* Q, int64_t ldq, int32_t T, int32_t R, int32_t N,
+                          float* C, int64_t ldc, int32_t transpose_out, float* partial_ws, int64_t partial_ws_floats,
+                          void* stream);
 /* LoRA (vla-scripts/finetune.py:174-189): out = bf16(s * x) for the small rank-space tensors; gradient mask that keeps
  * the off-block entries of a fused adapter's B [n_rows, members * rp] at zero (row n belongs to member n / (n_rows /
  * members), or n % members when the members' rows are interleaved). */

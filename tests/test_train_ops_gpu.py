@@ -256,3 +256,17 @@ def test_fast_transpose_and_transpose_pack(dev, rows, cols):
     t2 = torch.empty(sub.shape[1], rp, dtype=torch.bfloat16, device=dev)
     T.transpose_pad(sub, t2, rp)
     assert torch.equal(t2.cpu().float()[:, :rows], sub.cpu().float().t())
+
+
+@pytest.mark.parametrize("Tn,R,N,trans", [(300, 64, 192, False), (4608, 192, 4096, True), (1000, 128, 1088, True), (77, 64, 64, False),
+                                          (4608, 64, 22016, False)])
+def test_gemm_tn_small(dev, Tn, R, N, trans):
+    """C = Pᵀ·Q over the rows (LoRA adapter gradients), with and without the split-T workspace."""
+    from bridgelang_amd import train_ops as T
+    P_, Q_ = rand_bf16((Tn, R), Tn + R), rand_bf16((Tn, N), N)
+    ref = P_.t() @ Q_
+    ref = ref.t().contiguous() if trans else ref
+    for ws in (None, torch.empty(4 << 20, device=dev)):
+        C = torch.full(ref.shape, float("nan"), device=dev)
+        T.gemm_tn_small(dv(P_, dev), dv(Q_, dev), C, trans, ws)
+        assert torch.allclose(C.cpu(), ref, rtol=1e-4, atol=1e-4 * ref.abs().max().item()), (C.cpu() - ref).abs().max()

@@ -27,7 +27,12 @@ def main():
     dims = tiny_dims() if a.tiny else openvla_7b_dims()
     t0 = time.time()
     w = allocate(dims, dev).fill_synthetic(seed=0)
-    ts = TrainStep(w, a.stage, a.batch, a.len, max_grad_norm=1.0, weight_decay=0.0)
+    lora = None
+    if a.stage == "lora":
+        from bridgelang_amd.training.lora import LoraAdapters
+        lora = LoraAdapters(w, r=32)
+    ts = TrainStep(w, a.stage, a.batch, a.len, max_grad_norm=1.0 if lora is None else float("inf"),
+                   weight_decay=0.0 if lora is None else 0.01, lora=lora)
     torch.cuda.synchronize()
     print(f"setup {time.time() - t0:.1f}s; trainable {ts.store.n_params / 1e9:.3f} B params; "
           f"HBM in use {torch.cuda.memory_allocated() / 2**30:.1f} GiB", flush=True)
@@ -62,7 +67,9 @@ def main():
     wall = (time.time() - t0) / a.steps * 1e3
     for k in phases:
         phases[k] /= a.steps
-    fl = sum(op.flops for op in ts.forward_ops + ts.backward_ops) + sum(op.flops for op in ts._vis.vision_ops)
+    fl = sum(op.flops for op in ts.forward_ops + ts.backward_ops + ts.vision_forward_ops)
+    if not ts.train_vision:
+        fl += sum(op.flops for op in ts._vis.vision_ops)
     tokens = B * ts.S
     out = {"workload": f"{dims.name} {a.stage} B={B} S={ts.S}", "ms_per_step": wall, "phases_ms": phases,
            "samples_per_s": B / wall * 1e3, "tokens_per_s": tokens / wall * 1e3, "tflop_per_step": fl / 1e12,
