@@ -136,3 +136,34 @@ def test_replicas_gloo_world2(tmp_path):
     lines = sorted(l for o in outs for l in o.splitlines() if l.startswith("RESULT"))
     assert lines[0] == "RESULT 0 2 2.0 0 8 [9, 108]", lines
     assert lines[1] == "RESULT 1 2 2.0 9 16 [9, 108]", lines
+
+
+def test_registries_and_checkpoint_naming():
+    """Reference ids resolve (models/materialize.py:29-73), unknown ids raise its ValueError; native ↔ HF key maps are
+    inverse bijections over every tensor of the model (convert_openvla_weights_to_hf.py:73-115)."""
+    from bridgelang_amd.models.materialize import LLM_BACKBONES, VISION_BACKBONES, get_llm_backbone_and_tokenizer, get_vision_backbone_and_transform
+    from bridgelang_amd.training.checkpoint import from_model_state_dicts, hf_to_prismatic, prismatic_to_hf, to_model_state_dicts
+    from bridgelang_amd import weights as W
+    assert "dinosiglip-vit-so-224px" in VISION_BACKBONES and "llama2-7b-pure" in LLM_BACKBONES
+    vb, tf = get_vision_backbone_and_transform("dinosiglip-vit-so-224px", "resize-naive")
+    assert (vb.embed_dim, vb.num_patches, vb.default_image_resolution) == (2176, 256, (3, 224, 224)) and callable(tf)
+    lb, tok = get_llm_backbone_and_tokenizer("llama2-7b-pure", llm_max_length=2048, tokenizer="tok")
+    assert tok == "tok" and lb.embed_dim == 4096 and lb.pad_token_id == 32000 and lb.prompt_builder_fn.__name__ == "PurePromptBuilder"
+    assert lb.last_layer_finetune_modules[1] == "language_model.model.layers.31"
+    with pytest.raises(ValueError):
+        get_vision_backbone_and_transform("clip-vit-l", "resize-naive")
+    with pytest.raises(ValueError):
+        get_llm_backbone_and_tokenizer("phi-2-3b")
+    with pytest.raises(RuntimeError):
+        vb.forward(torch.zeros(1, 6, 224, 224))                  # not bound to a VLM
+    names = [s.name for s in W.tensor_specs(W.tiny_dims())]
+    seen = set()
+    for n in names:
+        m, k = hf_to_prismatic(n)
+        assert prismatic_to_hf(m, k) == n and (m, k) not in seen
+        seen.add((m, k))
+    assert hf_to_prismatic("projector.fc2.bias") == ("projector", "projector.2.bias")
+    assert hf_to_prismatic("vision_backbone.featurizer.blocks.0.ls1.scale_factor") == ("vision_backbone", "dino_featurizer.blocks.0.ls1.gamma")
+    assert hf_to_prismatic("language_model.lm_head.weight") == ("llm_backbone", "llm.lm_head.weight")
+    sd = {n: torch.zeros(1) for n in names}
+    assert set(from_model_state_dicts(to_model_state_dicts(sd, ["vision_backbone", "projector", "llm_backbone"]))) == set(names)
