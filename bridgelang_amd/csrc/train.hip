@@ -683,14 +683,40 @@ extern "C" int bl_layerscale_backward_bf16(const bl_bf16* dy, int64_t lddy, cons
 }
 
 // plain device memset / copy as replayable ops of the step plans (gradient buffers that are accumulated into, small
-// gradient slots that are filled from a shared scratch)
+// gradient slots that are filled from a shared scratch). Kernels, not hipMemsetAsync / hipMemcpyAsync: inside a captured
+// HIP graph the runtime's memset / copy nodes were observed to run out of order with the neighbouring kernel nodes
+// (7B full-train step replayed as a graph: garbage vision-tower gradients; eager and kernel-only graphs are exact).
+__global__ void zero_bytes_kernel(uint8_t* dst, long bytes) {
+  const long n16 = bytes >> 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x)
+    ((u32x4_t*)dst)[i] = (u32x4_t){0u, 0u, 0u, 0u};
+  for (long i = (n16 << 4) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < bytes; i += (long)gridDim.x * blockDim.x) dst[i] = 0;
+}
+__global__ void copy_bytes_kernel(uint8_t* dst, const uint8_t* src, long bytes, int vec) {
+  if (vec) {
+    const long n16 = bytes >> 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x)
+      ((u32x4_t*)dst)[i] = ((const u32x4_t*)src)[i];
+    for (long i = (n16 << 4) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < bytes; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < bytes; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+  }
+}
 extern "C" int bl_memset_zero(void* dst, int64_t bytes, void* stream) {
   if (!dst || bytes <= 0) return BL_E_ARG;
-  return hipMemsetAsync(dst, 0, (size_t)bytes, (hipStream_t)stream) == hipSuccess ? BL_OK : BL_E_LAUNCH;
+  if (((uintptr_t)dst) & 15) return BL_E_ALIGN;
+  hipLaunchKernelGGL(zero_bytes_kernel, dim3(grid_for((bytes + 15) / 16, 256)), dim3(256), 0, (hipStream_t)stream, (uint8_t*)dst,
+                     (long)bytes);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
 }
 extern "C" int bl_copy_bytes(void* dst, const void* src, int64_t bytes, void* stream) {
   if (!dst || !src || bytes <= 0) return BL_E_ARG;
-  return hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? BL_OK : BL_E_LAUNCH;
+  const int vec = ((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0;
+  hipLaunchKernelGGL(copy_bytes_kernel, dim3(grid_for(vec ? (bytes + 15) / 16 : bytes, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (uint8_t*)dst, (const uint8_t*)src, (long)bytes, vec);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
 }
 
 extern "C" int bl_scale_bf16(const bl_bf16* x, float s, bl_bf16* out, int64_t n, void* stream) {
@@ -716,8 +742,13 @@ extern "C" int bl_colsum_bf16(const bl_bf16* a, int64_t lda, int32_t rows, int32
                               int64_t partial_ws_floats, void* stream) {
   if (!a || !out || !partial_ws) return BL_E_ARG;
   if (rows <= 0 || cols <= 0 || (cols % 8) || (lda % 8)) return BL_E_SHAPE;
-  const int rpb = 256, nblk = (rows + rpb - 1) / rpb;
-  if (partial_ws_floats < (int64_t)nblk * cols) return BL_E_SHAPE;
+  // rows per block: as few as the workspace allows (>= 16) so the grid covers the chip even for narrow matrices
+  int rpb = 16;
+  while ((int64_t)((rows + rpb - 1) / rpb) * cols > partial_ws_floats) {
+    rpb *= 2;
+    if (rpb > (1 << 20)) return BL_E_SHAPE;
+  }
+  const int nblk = (rows + rpb - 1) / rpb;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, (cols / 8 + 255) / 256), dim3(256), 0, s, a, (long)lda, rows, cols,
                      rpb, partial_ws);

@@ -65,13 +65,13 @@ def finetune(vlm, dataloader: Iterable[Dict[str, Any]], action_tokenizer, cfg: F
                                max_grad_norm=float("inf"), weight_decay=0.01)      # AdamW(params, lr): torch defaults
             store = engine.store
         engine.set_batch(ids, batch["attention_mask"], batch["pixel_values"], batch["labels"])
-        loss = engine.forward()
-        engine.backward()
+        loss = engine.forward(graph=True)
+        engine.backward(graph=True)
         logits = engine.logits.view(engine.B, engine.S, -1)[:, :num_patches + ids.shape[1]]
         m = vla_action_metrics(logits, batch["labels"], action_tokenizer, num_patches=num_patches)
         recent["loss"].append(float(loss)); recent["acc"].append(m["action_accuracy"]); recent["l1"].append(m["l1_loss"])
         engine.clip_grad_norm()                       # max_norm = inf: only feeds the (unit) coefficient AdamW reads
-        engine.optimizer_step(cfg.learning_rate)
+        engine.optimizer_step(cfg.learning_rate, graph=True)
         step = batch_idx // cfg.grad_accumulation_steps
         sm = {k: sum(v) / len(v) for k, v in recent.items()}
         out.update(steps=step + 1, train_loss=sm["loss"], action_accuracy=sm["acc"], l1_loss=sm["l1"])

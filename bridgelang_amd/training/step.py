@@ -280,7 +280,7 @@ class TrainStep:
         mv = max((B * tw.dims.tokens for tw in towers), default=0)
         dv_ = max((tw.dims.dim for tw in towers), default=0)
         self.norm_ws = z(max(((Tn + 15) // 16) * D, 2 * ((mv + 15) // 16) * dv_), dtype=torch.float32)
-        self.col_ws = z(max(((Tn + 255) // 256) * max(Pv, D), 256 * dv_, ((mv + 63) // 64) * dv_ * 4), dtype=torch.float32)
+        self.col_ws = z(max(((Tn + 31) // 32) * max(Pv, D), 256 * dv_, ((mv + 15) // 16) * dv_ * 4), dtype=torch.float32)
         self._frozen_dw = z(2 * max(D, Pv, dv_), dtype=torch.float32)         # sink for vector grads of frozen tensors
         self._lora_t: Dict[int, torch.Tensor] = {}                            # saved t = x·Aᵀ per adapted linear
         self.dfeats = z(B * 256, d.vision_dim) if self.train_vision else None

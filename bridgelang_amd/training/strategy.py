@@ -229,9 +229,9 @@ class ShardedOptimizerStrategy:
                 continue                                                    # ragged tail of a finite iterable
             eng = self._ensure_engine(ids.shape[1])
             eng.set_batch(ids, batch["attention_mask"], batch["pixel_values"], batch["labels"])
-            loss = eng.forward()
+            loss = eng.forward(graph=True)                    # static plans replayed as HIP graphs
             metrics.commit(loss=loss)
-            eng.backward()
+            eng.backward(graph=True)                          # (sharded runs keep the backward eager: per-bucket collectives)
             # action metrics (base_strategy.py:314-329) on the positions this batch really has
             S_b = num_patches + ids.shape[1]
             logits = eng.logits.view(eng.B, eng.S, -1)[:, :S_b]
@@ -249,7 +249,7 @@ class ShardedOptimizerStrategy:
             self.clip_grad_norm()
             lr = lr_at(metrics.global_step, self.learning_rate, self.lr_scheduler_type, self.num_training_steps,
                        self.num_warmup_steps)
-            eng.optimizer_step(lr)
+            eng.optimizer_step(lr, graph=True)
             try:
                 epoch = (metrics.global_step + 1) // (len(vla_dataset) // self.global_batch_size)
             except (TypeError, ZeroDivisionError):

@@ -189,7 +189,8 @@ int bl_layernorm_backward_bf16(const bl_bf16* x, int64_t ldx, const bl_bf16* w, 
                                const bl_bf16* dres, int64_t lddres, bl_bf16* dx, int64_t lddx, float* dw, float* db,
                                float* partial_ws, int64_t partial_ws_floats, int32_t rows, int32_t dim, float eps,
                                void* stream);
-/* out[c] = sum_r a[r][c] (bias gradients). partial_ws >= ceil(rows/256)*cols floats. */
+/* out[c] = sum_r a[r][c] (bias gradients). partial_ws >= ceil(rows/rpb)*cols floats for some rpb = 16, 32, 64, ...: the smallest
+ * that fits is used (more room = more workgroups). */
 int bl_colsum_bf16(const bl_bf16* a, int64_t lda, int32_t rows, int32_t cols, float* out, float* partial_ws,
                    int64_t partial_ws_floats, void* stream);
 /* SwiGLU on an interleaved [rows, 2*inter] gate/up buffer (the training forward keeps it for the backward). */

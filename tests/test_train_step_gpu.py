@@ -116,3 +116,25 @@ def test_two_steps_match_torch_adamw(dev):
     live = w.state_dict()
     for n in names:
         assert torch.equal(live[n].float().cpu(), ts.store.named_master(n).to(torch.bfloat16).float().cpu()), n
+
+
+@pytest.mark.parametrize("stage", ["vla-train", "vla-full-train"])
+def test_graph_replay_equals_eager_over_steps(dev, stage):
+    """The three plans replayed as HIP graphs must reproduce the eager step bit for bit, step after step."""
+    from bridgelang_amd.training.step import TrainStep
+    from bridgelang_amd.weights import allocate, tiny_dims
+    dims = tiny_dims()
+    out = {}
+    for graph in (False, True):
+        w = allocate(dims, dev).fill_synthetic(seed=5)
+        ts = TrainStep(w, stage, 2, 18, max_grad_norm=1.0, weight_decay=0.1)
+        log = []
+        for step in range(5):
+            ids, mask, labels, pv = make_batch(dims, 2, 18, seed=30 + step)
+            ts.set_batch(ids, mask, pv, labels)
+            loss, norm = ts.step(1e-3, graph=graph)
+            log.append((loss.item(), norm.item()))
+        out[graph] = (log, ts.store.full_master().cpu())
+    print(out[False][0], out[True][0])
+    assert out[False][0] == out[True][0]
+    assert torch.equal(out[False][1], out[True][1])
