@@ -142,11 +142,29 @@ class OpenVLAEngine:
         x = self.x.view(B * S, D)
         plan = [ops.embed_splice(self.input_ids, w.embed, self.x, d.n_patches, run=False)]
         cs = (H * self.cache_len * hd, self.cache_len * hd, hd)
+        # Generation consumes only the last position of the last layer (the reference materialises all S rows of every
+        # layer): that layer still projects K/V for every position (the decode steps attend to them),
+        # but its attention, o_proj, MLP run on the B last rows only — single-query attention + weight-streaming GEMMs.
+        last_rows_only = not self.all_rows and d.llm_layers > 1
         for l, lw in enumerate(w.layers):
             plan.append(ops.rmsnorm(x, lw.ln1, self.h, d.rms_eps, run=False))
             plan.append(self._g(self.h, lw.qkv_w, self.qkv, EPI_NONE, run=False))
             plan.append(ops.rope_kvcache(self.qkv, self.cos, self.sin, self.k_cache[l], self.v_cache[l], B=B, S=S, H=H,
                                          head_dim=hd, pos0=0, run=False))
+            if last_rows_only and l == d.llm_layers - 1:
+                q_last = self.qkv.view(B, S, 3 * D)[:, S - 1]                  # roped in place; row stride S·3D
+                x_last = self.x[:, S - 1, :]
+                plan.append(ops.attention_decode(q_last, self.k_cache[l], self.v_cache[l], self.aod, B=B, H=H, Skv=S,
+                                                 head_dim=hd, q_strides=(S * 3 * D, hd, 3 * D), k_strides=cs, v_strides=cs,
+                                                 o_strides=(D, hd, D), run=False))
+                plan.append(self._g(self.aod, lw.o_w, self.xd, EPI_RES, res=x_last, run=False))
+                if ops.skinny_supported(B, D, EPI_SWIGLU):
+                    plan.append(self._g(self.xd, lw.gu_w, self.actd, EPI_SWIGLU, a_norm=(lw.ln2, d.rms_eps), run=False))
+                else:
+                    plan.append(ops.rmsnorm(self.xd, lw.ln2, self.hd, d.rms_eps, run=False))
+                    plan.append(self._g(self.hd, lw.gu_w, self.actd, EPI_SWIGLU, run=False))
+                plan.append(self._g(self.actd, lw.down_w, self.xd, EPI_RES, res=self.xd, run=False))
+                return plan + self._head(self.xd, 0)
             plan.append(ops.attention(self.qkv, self.k_cache[l], self.v_cache[l], self.ao, B=B, H=H, Sq=S, Skv=S,
                                       head_dim=hd, q_strides=(S * 3 * D, hd, 3 * D), k_strides=cs, v_strides=cs,
                                       o_strides=(S * D, hd, D), causal=True, key_mask=self.key_mask, run=False))
