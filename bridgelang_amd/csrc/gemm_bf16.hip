@@ -116,10 +116,17 @@ __global__ __launch_bounds__(256) void gemm128_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BK;
-  BL_STAGE(0, 0);
+  // few-tile problems (tall-skinny: LoRA rank projections, small ViT shapes): grid.y slices K; every slice writes an fp32
+  // partial [M, N] to the slab, gemm128_splitk_reduce_kernel sums them in slice order and applies the epilogue
+  const int nk_all = p.K / BK;
+  int kt0 = 0, nk = nk_all;
+  if (p.splitk > 1 && p.tail_base < 0) {
+    kt0 = (int)(((long)blockIdx.y * nk_all) / p.splitk);
+    nk = (int)(((long)(blockIdx.y + 1) * nk_all) / p.splitk);
+  }
+  BL_STAGE(kt0 & 1, kt0);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) BL_STAGE(cur ^ 1, kt + 1);
     const char* base = smem + cur * BUF_BYTES;
@@ -140,11 +147,37 @@ __global__ __launch_bounds__(256) void gemm128_kernel(GemmArgs p) {
     __syncthreads();
   }
 #undef BL_STAGE
+  if (p.splitk > 1 && p.tail_base < 0) {
+    float* slab = p.slab + (long)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int m = m0 + wm * TM + j * 16 + l15, n = n0 + wn * TN + i * 16 + lg * 4;
+        if (m < p.M && n < p.N) *(f32x4_t*)(slab + (long)m * p.N + n) = acc[i][j];
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int j = 0; j < MT; ++j)
       epilogue_store4<EPI>(p, m0 + wm * TM + j * 16 + l15, n0 + wn * TN + i * 16 + lg * 4, acc[i][j]);
+#endif
+}
+
+// out(m, n..n+3) = epilogue(Σ_slices slab[slice][m][n..n+3]) for the split-K form of the 128 kernel
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm128_splitk_reduce_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int n4 = p.N >> 2;
+  const long total = (long)p.M * n4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
+    f32x4_t sum = *(const f32x4_t*)(p.slab + (long)m * p.N + n);
+    for (int s2 = 1; s2 < p.splitk; ++s2) sum += *(const f32x4_t*)(p.slab + ((long)s2 * p.M + m) * p.N + n);
+    epilogue_store4<EPI>(p, m, n, sum);
+  }
 #endif
 }
 
@@ -556,7 +589,22 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (!big) {
     p.tiles_m = (p.M + 127) / 128;
     p.tiles_n = (p.N + 127) / 128;
-    hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(p.tiles_m * p.tiles_n), dim3(256), LDS128, s, p);
+    const int tiles = p.tiles_m * p.tiles_n, nk128 = p.K / BK;
+    // few tiles, long K (tall-skinny): slice K over grid.y when the caller gave a workspace (opt-in, as for the 256
+    // kernel: sliced sums are not batch-slot invariant)
+    int S128 = 1;
+    if (p.slab && tiles <= CUS / 2 && !force && !getenv("BL_GEMM_NO_SPLITK")) {
+      S128 = min(8, (2 * CUS) / tiles);
+      while (S128 > 1 && (nk128 / S128 < 8 || p.slab_bytes < (long)S128 * p.M * p.N * 4)) --S128;
+    }
+    if (S128 > 1) {
+      p.splitk = S128;
+      hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(tiles, S128), dim3(256), LDS128, s, p);
+      const long work = (long)p.M * (p.N / 4);
+      hipLaunchKernelGGL((gemm128_splitk_reduce_kernel<EPI>), dim3((int)min((work + 255) / 256, 2048L)), dim3(256), 0, s, p);
+    } else {
+      hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(tiles), dim3(256), LDS128, s, p);
+    }
     BL_CHECK_LAUNCH();
     return BL_OK;
   }

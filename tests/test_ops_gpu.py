@@ -109,7 +109,10 @@ def test_gemm_none_bias_gelu(dev, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(4608, 4096, 512, "res"), (4608, 1024, 1024, "gelu"), (4400, 3584, 768, "swiglu"),
-                                       (4608, 12288, 256, "none")])
+                                       (4608, 12288, 256, "none"),
+                                       # few-tile (tall-skinny) problems: the 128 kernel slices K over grid.y
+                                       (4608, 64, 4096, "none"), (4176, 192, 3072, "res"), (300, 128, 2048, "gelu"),
+                                       (1000, 256, 1536, "swiglu")])
 def test_gemm_splitk_tail(dev, M, N, K, epi):
     """Shapes whose 256x256 tile count is not a multiple of 256: whole rounds + split-K tail (with a workspace) must
     equal the oracle, and equal the no-workspace dispatch bit for bit except for fp32 summation order."""
