@@ -82,18 +82,20 @@ SIGNATURES = {
     "bl_colsum_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
     "bl_swiglu_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "bl_swiglu_backward_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
-    "bl_gelu_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
-    "bl_gelu_backward_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
-    "bl_rope_backward_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "bl_gelu_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp]),
+    "bl_gelu_backward_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
+    "bl_rope_backward_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "bl_transpose_pad_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "bl_pack_weight_into_bf16": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp]),
+    "bl_transpose_pack_into_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i32, _i64, _i64, _vp]),
     "bl_transpose_pack_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "bl_sumsq_partial_f32": (C.c_int, [_vp, _i64, _vp, _i32, _vp]),
     "bl_clip_coef_f32": (C.c_int, [_vp, _i32, _f32, _vp, _vp]),
     "bl_adamw_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
-    "bl_rope_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "bl_rope_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "bl_scale_residual_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "bl_layerscale_backward_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp]),
-    "bl_gemm_tn_small_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _i32, _vp, _i64, _vp]),
+    "bl_gemm_tn_small_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _i32, _f32, _vp, _i64, _vp]),
     "bl_scale_bf16": (C.c_int, [_vp, _f32, _vp, _i64, _vp]),
     "bl_lora_block_mask_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "bl_memset_zero": (C.c_int, [_vp, _i64, _vp]),

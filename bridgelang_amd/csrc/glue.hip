@@ -32,7 +32,7 @@ __global__ void fill_synth_kernel(uint16_t* dst, long rows, long cols, long ld, 
 // HF apply_rotary_pos_emb in bf16: q' = bf16(bf16(q*cos) + bf16(rotate_half(q)*sin)), rotate_half = cat(-x2, x1).
 __global__ void rope_kvcache_kernel(uint16_t* qkv, int B, int S, int H, int hd, const uint16_t* cos_tab,
                                     const uint16_t* sin_tab, int pos0, uint16_t* k_cache, uint16_t* v_cache,
-                                    int cache_len) {
+                                    int cache_len, long ld) {
   const int half = hd >> 1, cpr = half >> 3;          // 16-byte chunks per half head
   const long total = (long)B * S * H * cpr;
   const long D = (long)H * hd;
@@ -44,7 +44,7 @@ __global__ void rope_kvcache_kernel(uint16_t* qkv, int B, int S, int H, int hd, 
     const int pos = pos0 + s;
     const u32x4_t cq = *(const u32x4_t*)(cos_tab + (long)pos * half + ch * 8);
     const u32x4_t sq = *(const u32x4_t*)(sin_tab + (long)pos * half + ch * 8);
-    uint16_t* row = qkv + tok * 3 * D;
+    uint16_t* row = qkv + tok * ld;
     const long cache_off = (((long)b * H + h) * cache_len + pos) * hd;
 #pragma unroll
     for (int part = 0; part < 2; ++part) {             // 0 = q (in place), 1 = k (→ cache)
@@ -214,14 +214,16 @@ __global__ __launch_bounds__(256) void masked_mean_kernel(const float* row_loss,
 // One 16-byte chunk per thread: packed chunk (nt, ks, lane) = W[16*nt + (lane & 15)][32*ks + 8*(lane >> 4) .. +7], i.e.
 // exactly what lane `lane` feeds v_mfma_f32_16x16x32_bf16 for weight tile nt, k-step ks. Every (nt, ks) block is one
 // contiguous KiB, so decode streams weights with whole-line requests and LDS-DMA lands them already in read order.
-__global__ void pack_weight_kernel(const uint16_t* src, long ld, long n, long k, uint16_t* dst) {
+// kt_total / kb_off: the destination's k-blocks per n-tile and the first k-block written (a [n, k] matrix packed into
+// columns [32·kb_off, 32·kb_off + k) of a wider packed matrix: the adapter columns of a K-concatenated LoRA weight)
+__global__ void pack_weight_kernel(const uint16_t* src, long ld, long n, long k, uint16_t* dst, long kt_total, long kb_off) {
   const long ks_n = k >> 5;
   const long total = (n >> 4) * ks_n * 64;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int lane = (int)(i & 63);
     const long blk = i >> 6, ks = blk % ks_n, nt = blk / ks_n;
     const long row = nt * 16 + (lane & 15), col = ks * 32 + (lane >> 4) * 8;
-    *(u32x4_t*)(dst + i * 8) = *(const u32x4_t*)(src + row * ld + col);
+    *(u32x4_t*)(dst + ((nt * kt_total + kb_off + ks) * 64 + lane) * 8) = *(const u32x4_t*)(src + row * ld + col);
   }
 }
 
@@ -250,7 +252,19 @@ extern "C" int bl_pack_weight_bf16(const bl_bf16* src, int64_t ld, int64_t n, in
   if (n <= 0 || k <= 0 || (n % 16) || (k % 32) || ld < k) return BL_E_SHAPE;
   if ((ld % 8) || !bl_aligned16(src) || !bl_aligned16(dst)) return BL_E_ALIGN;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(n * k / 8, 256)), dim3(256), 0, (hipStream_t)stream, src,
-                     (long)ld, (long)n, (long)k, dst);
+                     (long)ld, (long)n, (long)k, dst, (long)(k / 32), 0L);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_pack_weight_into_bf16(const bl_bf16* src, int64_t ld, int64_t n, int64_t k, bl_bf16* dst, int64_t kt_total,
+                                        int64_t kb_offset, void* stream) {
+  if (!src || !dst) return BL_E_ARG;
+  if (n <= 0 || k <= 0 || (n % 16) || (k % 32) || ld < k || (ld % 8) || kb_offset < 0 || kb_offset + k / 32 > kt_total)
+    return BL_E_SHAPE;
+  if (!bl_aligned16(src) || !bl_aligned16(dst)) return BL_E_ALIGN;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(n * k / 8, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     (long)ld, (long)n, (long)k, dst, (long)kt_total, (long)kb_offset);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }
@@ -269,19 +283,19 @@ extern "C" int bl_rope_kvcache_bf16(bl_bf16* qkv, int32_t B, int32_t S, int32_t 
     return BL_E_ALIGN;
   const long total = (long)B * S * H * (hd / 16);
   hipLaunchKernelGGL(rope_kvcache_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, qkv, B, S, H,
-                     hd, cos_tab, sin_tab, pos0, k_cache, v_cache, cache_len);
+                     hd, cos_tab, sin_tab, pos0, k_cache, v_cache, cache_len, 3L * H * hd);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }
 
-extern "C" int bl_rope_bf16(bl_bf16* qkv, int32_t B, int32_t S, int32_t H, int32_t hd, const bl_bf16* cos_tab,
+extern "C" int bl_rope_bf16(bl_bf16* qkv, int64_t ld, int32_t B, int32_t S, int32_t H, int32_t hd, const bl_bf16* cos_tab,
                             const bl_bf16* sin_tab, int32_t pos0, void* stream) {
   if (!qkv || !cos_tab || !sin_tab) return BL_E_ARG;
-  if (B <= 0 || S <= 0 || H <= 0 || hd <= 0 || (hd % 16) || pos0 < 0) return BL_E_SHAPE;
+  if (B <= 0 || S <= 0 || H <= 0 || hd <= 0 || (hd % 16) || pos0 < 0 || ld < 3L * H * hd || (ld % 8)) return BL_E_SHAPE;
   if (!bl_aligned16(qkv) || !bl_aligned16(cos_tab) || !bl_aligned16(sin_tab)) return BL_E_ALIGN;
   const long total = (long)B * S * H * (hd / 16);
   hipLaunchKernelGGL(rope_kvcache_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, qkv, B, S, H,
-                     hd, cos_tab, sin_tab, pos0, (uint16_t*)nullptr, (uint16_t*)nullptr, 0);
+                     hd, cos_tab, sin_tab, pos0, (uint16_t*)nullptr, (uint16_t*)nullptr, 0, (long)ld);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

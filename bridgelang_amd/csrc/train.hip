@@ -238,29 +238,38 @@ __global__ void swiglu_bwd_kernel(const uint16_t* gu, long ldg, const uint16_t* 
 }
 
 // ---- exact-erf GELU forward / backward (projector; training keeps the pre-activation) ----
-__global__ void gelu_fwd_kernel(const uint16_t* x, uint16_t* y, long n8) {
+__global__ void gelu_fwd_kernel(const uint16_t* x, long ldx, uint16_t* y, long ldy, long rows, int cols) {
+  const int cpr = cols >> 3;
+  const long n8 = rows * cpr;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += (long)gridDim.x * blockDim.x) {
+    const long r = t / cpr;
+    const int c = (int)(t - r * cpr) * 8;
     float v[8];
-    unpack8(*(const u32x4_t*)(x + t * 8), v);
+    unpack8(*(const u32x4_t*)(x + r * ldx + c), v);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i]);
-    *(u32x4_t*)(y + t * 8) = pack8(v);
+    *(u32x4_t*)(y + r * ldy + c) = pack8(v);
   }
 }
-__global__ void gelu_bwd_kernel(const uint16_t* x, const uint16_t* dy, uint16_t* dx, long n8) {
+__global__ void gelu_bwd_kernel(const uint16_t* x, long ldx, const uint16_t* dy, long lddy, uint16_t* dx, long lddx, long rows,
+                                int cols) {
+  const int cpr = cols >> 3;
+  const long n8 = rows * cpr;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += (long)gridDim.x * blockDim.x) {
+    const long r = t / cpr;
+    const int c = (int)(t - r * cpr) * 8;
     float v[8], d[8];
-    unpack8(*(const u32x4_t*)(x + t * 8), v);
-    unpack8(*(const u32x4_t*)(dy + t * 8), d);
+    unpack8(*(const u32x4_t*)(x + r * ldx + c), v);
+    unpack8(*(const u32x4_t*)(dy + r * lddy + c), d);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       d[i] *= 0.5f * (1.0f + erff(v[i] * 0.70710678118654752440f)) + v[i] * 0.39894228040143267794f * expf(-0.5f * v[i] * v[i]);
-    *(u32x4_t*)(dx + t * 8) = pack8(d);
+    *(u32x4_t*)(dx + r * lddx + c) = pack8(d);
   }
 }
 
 // ---- RoPE backward on the q and k thirds of a fused dqkv buffer [B*S, 3*H*hd] (transpose of the rotation) ----
-__global__ void rope_bwd_kernel(uint16_t* dqkv, int B, int S, int H, int hd, const uint16_t* cos_tab,
+__global__ void rope_bwd_kernel(uint16_t* dqkv, long ld, int B, int S, int H, int hd, const uint16_t* cos_tab,
                                 const uint16_t* sin_tab, int pos0) {
   const int half = hd >> 1, cpr = half >> 3;
   const long total = (long)B * S * H * cpr * 2;
@@ -274,7 +283,7 @@ __global__ void rope_bwd_kernel(uint16_t* dqkv, int B, int S, int H, int hd, con
     float c[8], s[8], d1[8], d2[8], o1[8], o2[8];
     unpack8(*(const u32x4_t*)(cos_tab + (long)pos * half + ch * 8), c);
     unpack8(*(const u32x4_t*)(sin_tab + (long)pos * half + ch * 8), s);
-    uint16_t* p = dqkv + tok * 3 * D + part * D + (long)h * hd + ch * 8;
+    uint16_t* p = dqkv + tok * ld + part * D + (long)h * hd + ch * 8;
     unpack8(*(const u32x4_t*)p, d1);
     unpack8(*(const u32x4_t*)(p + half), d2);
 #pragma unroll
@@ -387,7 +396,7 @@ __device__ __forceinline__ int tr_swz(int row) { return ((row >> 1) & 1) | (((ro
 
 template <bool PACKED>
 __global__ __launch_bounds__(256) void transpose_fast_kernel(const uint16_t* in, long ldi, int rows, int cols,
-                                                             uint16_t* out, long ldo, int rows_pad) {
+                                                             uint16_t* out, long ldo, int rows_pad, long kt_total, long kb_off) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(16))) char tile[256 * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(256) void transpose_fast_kernel(const uint16_t* in,
     }
     const u32x4_t o = {w[0][0], w[0][1], w[1][0], w[1][1]};      // 8 consecutive rows t = r0 + 32 tb + 8 lg + j of column `col`
     if (PACKED) {
-      const long unit = ((long)(c0 / 16 + wave) * (rows_pad / 32) + (r0 / 32 + tb)) * 64 + lane;
+      const long unit = ((long)(c0 / 16 + wave) * kt_total + kb_off + (r0 / 32 + tb)) * 64 + lane;
       *(u32x4_t*)(out + unit * 8) = o;
     } else {
       *(u32x4_t*)(out + (long)col * ldo + r0 + tb * 32 + 8 * lg) = o;
@@ -437,7 +446,7 @@ __device__ __forceinline__ int tr_swz8(int row) { return (row & 3) | (((row >> 3
 
 template <int R, bool TRANS>
 __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const uint16_t* P, long ldp, const uint16_t* Q, long ldq, int T,
-                                                            int N, float* C, long ldc, int t_per_split, long split_stride) {
+                                                            int N, float* C, long ldc, int t_per_split, long split_stride, float alpha) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int RB = R / 16, PROW = R * 2, PCH = R / 8;          // P tile: 32 rows × PROW bytes, PCH 16-byte chunks per row
   constexpr int PLD = (32 * PCH + 255) / 256;                    // 16-byte P loads per thread per step
@@ -511,9 +520,9 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const uint16_t* P, l
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     if (TRANS) {   // acc: rows r = 16 rb + 4 lg + reg, column n = n0 + 16 wave + l15  →  C[n][r..r+3]
-      *(f32x4_t*)(Cs + (long)(n0 + 16 * wave + l15) * ldc + rb * 16 + lg * 4) = acc[rb];
+      *(f32x4_t*)(Cs + (long)(n0 + 16 * wave + l15) * ldc + rb * 16 + lg * 4) = acc[rb] * alpha;
     } else {       // acc: rows n = n0 + 16 wave + 4 lg + reg, column r = 16 rb + l15   →  C[r][n..n+3]
-      *(f32x4_t*)(Cs + (long)(rb * 16 + l15) * ldc + n0 + 16 * wave + lg * 4) = acc[rb];
+      *(f32x4_t*)(Cs + (long)(rb * 16 + l15) * ldc + n0 + 16 * wave + lg * 4) = acc[rb] * alpha;
     }
   }
 #endif
@@ -776,27 +785,30 @@ extern "C" int bl_swiglu_backward_bf16(const bl_bf16* gu, int64_t ldg, const bl_
   return BL_OK;
 }
 
-extern "C" int bl_gelu_bf16(const bl_bf16* x, bl_bf16* y, int64_t n, void* stream) {
+extern "C" int bl_gelu_bf16(const bl_bf16* x, int64_t ldx, bl_bf16* y, int64_t ldy, int64_t rows, int32_t cols, void* stream) {
   if (!x || !y) return BL_E_ARG;
-  if (n <= 0 || (n % 8)) return BL_E_SHAPE;
-  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, y, (long)(n / 8));
+  if (rows <= 0 || cols <= 0 || (cols % 8) || (ldx % 8) || (ldy % 8) || ldx < cols || ldy < cols) return BL_E_SHAPE;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(rows * (cols / 8), 256)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, y,
+                     (long)ldy, (long)rows, cols);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }
-extern "C" int bl_gelu_backward_bf16(const bl_bf16* x, const bl_bf16* dy, bl_bf16* dx, int64_t n, void* stream) {
+extern "C" int bl_gelu_backward_bf16(const bl_bf16* x, int64_t ldx, const bl_bf16* dy, int64_t lddy, bl_bf16* dx, int64_t lddx,
+                                     int64_t rows, int32_t cols, void* stream) {
   if (!x || !dy || !dx) return BL_E_ARG;
-  if (n <= 0 || (n % 8)) return BL_E_SHAPE;
-  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (long)(n / 8));
+  if (rows <= 0 || cols <= 0 || (cols % 8) || (ldx % 8) || (lddy % 8) || (lddx % 8)) return BL_E_SHAPE;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(rows * (cols / 8), 256)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, dy,
+                     (long)lddy, dx, (long)lddx, (long)rows, cols);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }
 
-extern "C" int bl_rope_backward_bf16(bl_bf16* dqkv, int32_t B, int32_t S, int32_t H, int32_t hd, const bl_bf16* cos_tab,
+extern "C" int bl_rope_backward_bf16(bl_bf16* dqkv, int64_t ld, int32_t B, int32_t S, int32_t H, int32_t hd, const bl_bf16* cos_tab,
                                      const bl_bf16* sin_tab, int32_t pos0, void* stream) {
   if (!dqkv || !cos_tab || !sin_tab) return BL_E_ARG;
-  if (B <= 0 || S <= 0 || H <= 0 || hd <= 0 || (hd % 16) || pos0 < 0) return BL_E_SHAPE;
+  if (B <= 0 || S <= 0 || H <= 0 || hd <= 0 || (hd % 16) || pos0 < 0 || ld < 3L * H * hd || (ld % 8)) return BL_E_SHAPE;
   const long total = (long)B * S * H * (hd / 16) * 2;
-  hipLaunchKernelGGL(rope_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, dqkv, B, S, H, hd,
+  hipLaunchKernelGGL(rope_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, dqkv, (long)ld, B, S, H, hd,
                      cos_tab, sin_tab, pos0);
   BL_CHECK_LAUNCH();
   return BL_OK;
@@ -819,7 +831,7 @@ extern "C" int bl_transpose_pad_bf16(const bl_bf16* in, int64_t ldi, int32_t row
   if (rows <= 0 || cols <= 0 || rows_pad < rows || ldo < rows_pad) return BL_E_SHAPE;
   if ((cols % 64) == 0 && (rows_pad % 32) == 0 && (ldi % 8) == 0 && (ldo % 8) == 0 && bl_aligned16(in) && bl_aligned16(out))
     hipLaunchKernelGGL((transpose_fast_kernel<false>), dim3((rows_pad + 255) / 256, cols / 64), dim3(256), 0,
-                       (hipStream_t)stream, in, (long)ldi, rows, cols, out, (long)ldo, rows_pad);
+                       (hipStream_t)stream, in, (long)ldi, rows, cols, out, (long)ldo, rows_pad, 0L, 0L);
   else
     hipLaunchKernelGGL(transpose_pad_kernel, dim3((rows_pad + 63) / 64, (cols + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                        in, (long)ldi, rows, cols, out, (long)ldo, rows_pad);
@@ -833,13 +845,26 @@ extern "C" int bl_transpose_pack_bf16(const bl_bf16* in, int64_t ldi, int32_t ro
   if (rows <= 0 || cols <= 0 || rows_pad < rows || (cols % 64) || (rows_pad % 32) || (ldi % 8)) return BL_E_SHAPE;
   if (!bl_aligned16(in) || !bl_aligned16(out_packed)) return BL_E_ALIGN;
   hipLaunchKernelGGL((transpose_fast_kernel<true>), dim3((rows_pad + 255) / 256, cols / 64), dim3(256), 0,
-                     (hipStream_t)stream, in, (long)ldi, rows, cols, out_packed, 0L, rows_pad);
+                     (hipStream_t)stream, in, (long)ldi, rows, cols, out_packed, 0L, rows_pad, (long)(rows_pad / 32), 0L);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_transpose_pack_into_bf16(const bl_bf16* in, int64_t ldi, int32_t rows, int32_t cols, bl_bf16* out_packed,
+                                           int32_t rows_pad, int64_t kt_total, int64_t kb_offset, void* stream) {
+  if (!in || !out_packed) return BL_E_ARG;
+  if (rows <= 0 || cols <= 0 || rows_pad < rows || (cols % 64) || (rows_pad % 32) || (ldi % 8) || kb_offset < 0 ||
+      kb_offset + rows_pad / 32 > kt_total)
+    return BL_E_SHAPE;
+  if (!bl_aligned16(in) || !bl_aligned16(out_packed)) return BL_E_ALIGN;
+  hipLaunchKernelGGL((transpose_fast_kernel<true>), dim3((rows_pad + 255) / 256, cols / 64), dim3(256), 0,
+                     (hipStream_t)stream, in, (long)ldi, rows, cols, out_packed, 0L, rows_pad, (long)kt_total, (long)kb_offset);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }
 
 extern "C" int bl_gemm_tn_small_bf16(const bl_bf16* P, int64_t ldp, const bl_bf16* Q, int64_t ldq, int32_t T, int32_t R,
-                                     int32_t N, float* C, int64_t ldc, int32_t transpose_out, float* partial_ws,
+                                     int32_t N, float* C, int64_t ldc, int32_t transpose_out, float alpha, float* partial_ws,
                                      int64_t partial_ws_floats, void* stream) {
   if (!P || !Q || !C) return BL_E_ARG;
   if (T <= 0 || (R != 64 && R != 128 && R != 192) || N <= 0 || (N % 64) || (ldp % 8) || (ldq % 8) || (ldc % 4)) return BL_E_SHAPE;
@@ -859,9 +884,9 @@ extern "C" int bl_gemm_tn_small_bf16(const bl_bf16* P, int64_t ldp, const bl_bf1
 #define BL_TN(RR)                                                                                                        \
   case RR:                                                                                                               \
     if (transpose_out) hipLaunchKernelGGL((gemm_tn_small_kernel<RR, true>), grid, block, 0, s, P, (long)ldp, Q, (long)ldq, T, N, \
-                                          out, (long)ldc, t_per, stride);                                                \
+                                          out, (long)ldc, t_per, stride, alpha);                                         \
     else hipLaunchKernelGGL((gemm_tn_small_kernel<RR, false>), grid, block, 0, s, P, (long)ldp, Q, (long)ldq, T, N, out, \
-                            (long)ldc, t_per, stride);                                                                   \
+                            (long)ldc, t_per, stride, alpha);                                                            \
     break;
   switch (R) { BL_TN(64) BL_TN(128) BL_TN(192) }
 #undef BL_TN

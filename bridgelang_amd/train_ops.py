@@ -61,27 +61,26 @@ def swiglu_backward(gu, dact, dgu, run: bool = True) -> Op:
 
 
 def gelu(x, y, run: bool = True) -> Op:
-    assert x.is_contiguous() and y.is_contiguous()
-    return _op("bl_gelu_bf16", (_bf16(x, "x").data_ptr(), _bf16(y, "y").data_ptr(), x.numel()), (x, y), run, nbytes=4.0 * x.numel())
+    rows, cols = x.shape
+    return _op("bl_gelu_bf16", (_bf16(x, "x").data_ptr(), _rows(x, "x"), _bf16(y, "y").data_ptr(), _rows(y, "y"), rows, cols), (x, y), run,
+               nbytes=4.0 * rows * cols)
 
 
 def gelu_backward(x, dy, dx, run: bool = True) -> Op:
-    assert x.is_contiguous() and dy.is_contiguous() and dx.is_contiguous()
-    return _op("bl_gelu_backward_bf16", (_bf16(x, "x").data_ptr(), _bf16(dy, "dy").data_ptr(), _bf16(dx, "dx").data_ptr(),
-                                         x.numel()), (x, dy, dx), run, nbytes=6.0 * x.numel())
+    rows, cols = x.shape
+    return _op("bl_gelu_backward_bf16", (_bf16(x, "x").data_ptr(), _rows(x, "x"), _bf16(dy, "dy").data_ptr(), _rows(dy, "dy"),
+                                         _bf16(dx, "dx").data_ptr(), _rows(dx, "dx"), rows, cols), (x, dy, dx), run, nbytes=6.0 * rows * cols)
 
 
 def rope(qkv, cos, sin, *, B: int, S: int, H: int, head_dim: int, pos0: int = 0, run: bool = True) -> Op:
-    """Rotate the q and k thirds of fused qkv rows in place (training forward: no KV cache)."""
-    assert qkv.is_contiguous()
-    return _op("bl_rope_bf16", (_bf16(qkv, "qkv").data_ptr(), B, S, H, head_dim, cos.data_ptr(), sin.data_ptr(), pos0),
+    """Rotate the q and k thirds of fused qkv rows [B*S, 3*H*hd] (leading dimension free) in place: no KV cache."""
+    return _op("bl_rope_bf16", (_bf16(qkv, "qkv").data_ptr(), _rows(qkv, "qkv"), B, S, H, head_dim, cos.data_ptr(), sin.data_ptr(), pos0),
                (qkv, cos, sin), run, nbytes=8.0 * B * S * H * head_dim)
 
 
 def rope_backward(dqkv, cos, sin, *, B: int, S: int, H: int, head_dim: int, pos0: int = 0, run: bool = True) -> Op:
-    assert dqkv.is_contiguous()
-    return _op("bl_rope_backward_bf16", (_bf16(dqkv, "dqkv").data_ptr(), B, S, H, head_dim, cos.data_ptr(), sin.data_ptr(), pos0),
-               (dqkv, cos, sin), run, nbytes=8.0 * B * S * H * head_dim)
+    return _op("bl_rope_backward_bf16", (_bf16(dqkv, "dqkv").data_ptr(), _rows(dqkv, "dqkv"), B, S, H, head_dim, cos.data_ptr(),
+                                         sin.data_ptr(), pos0), (dqkv, cos, sin), run, nbytes=8.0 * B * S * H * head_dim)
 
 
 def transpose_pad(a, out, rows_pad: int, run: bool = True) -> Op:
@@ -208,12 +207,28 @@ def transpose_pack(a: torch.Tensor, out_packed: torch.Tensor, rows_pad: int, run
 
 
 def gemm_tn_small(P: torch.Tensor, Q: torch.Tensor, C: torch.Tensor, transpose_out: bool, ws: Optional[torch.Tensor] = None,
-                  run: bool = True) -> Op:
-    """C = Pᵀ·Q over the rows: P [T, R] (R in 64/128/192), Q [T, N]; C fp32 [R, N] or, transposed, [N, R]."""
+                  alpha: float = 1.0, run: bool = True) -> Op:
+    """C = alpha · Pᵀ·Q over the rows: P [T, R] (R in 64/128/192), Q [T, N]; C fp32 [R, N] or, transposed, [N, R]."""
     Tn, R = P.shape
     N = Q.shape[1]
     assert Q.shape[0] == Tn and tuple(C.shape) == ((N, R) if transpose_out else (R, N)) and C.is_contiguous()
     return _op("bl_gemm_tn_small_bf16",
                (_bf16(P, "P").data_ptr(), _rows(P, "P"), _bf16(Q, "Q").data_ptr(), _rows(Q, "Q"), Tn, R, N, _f32(C, "C").data_ptr(),
-                C.shape[1], int(transpose_out), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0),
+                C.shape[1], int(transpose_out), float(alpha), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0),
                (P, Q, C, ws), run, flops=2.0 * Tn * R * N, nbytes=2.0 * Tn * (R + N) + 4.0 * R * N)
+
+
+def pack_into(w: torch.Tensor, out: torch.Tensor, kt_total: int, kb_offset: int, run: bool = True) -> Op:
+    """Row-major [N, K] → k-blocks [kb_offset, kb_offset + K/32) of the packed matrix `out` ([N/16, kt_total, 64, 8])."""
+    N, K = w.shape
+    assert out.numel() == N * kt_total * 32
+    return _op("bl_pack_weight_into_bf16", (_bf16(w, "w").data_ptr(), _rows(w, "w"), N, K, _bf16(out, "out").data_ptr(), kt_total,
+                                            kb_offset), (w, out), run, nbytes=4.0 * N * K)
+
+
+def transpose_pack_into(a: torch.Tensor, out: torch.Tensor, rows_pad: int, kt_total: int, kb_offset: int, run: bool = True) -> Op:
+    """[rows, cols] → the transposed matrix's k-blocks [kb_offset, …) of packed `out` ([cols/16, kt_total, 64, 8])."""
+    rows, cols = a.shape
+    assert out.numel() == cols * kt_total * 32
+    return _op("bl_transpose_pack_into_bf16", (_bf16(a, "a").data_ptr(), _rows(a, "a"), rows, cols, _bf16(out, "out").data_ptr(),
+                                               rows_pad, kt_total, kb_offset), (a, out), run, nbytes=2.0 * cols * (rows + rows_pad))

@@ -8,9 +8,14 @@ structured (member j's rows only see columns j·rp …), and the off-block entri
 gradients (bl_lora_block_mask_f32). The rank is zero-padded to rp = 64 (the GEMM kernels' K granularity); padded rows /
 columns have zero gradients by construction and stay zero.
 
-Forward of one linear (training/step.py::_lin):  t = x·Aᵀ;  y = bf16(bf16(bf16(t·Bᵀ)·s) + y)   — PEFT's order of roundings
-under bf16 autocast (lora_B output, × scaling, + base result).
-Backward: ts = s·t, dB = dyᵀ·ts, dt = s·(dy·B), dA = dtᵀ·x, dx += dt·A — all through the same GEMM kernels.
+Forward of one linear (training/step.py::_lin): t = x·Aᵀ is written into spare columns of x's buffer and the layer is ONE
+GEMM over K + R, y = bf16([x | t]·[W | s·B]ᵀ) — the rank-R update is accumulated in fp32 with the base product and rounded
+once. PEFT under bf16 autocast rounds lora_B's output, its product with the scaling and the sum with the base result
+separately; the two differ by at most one bf16 ulp of y, but the single rounding does not absorb updates that are below
+half an ulp of the base output (right after initialisation, B ≈ 0, PEFT's order loses most of them). s·B is stored as
+bf16(s·B) (exact for the reference's s = 0.5).
+Backward: dt = dy·(s·B) into spare columns of dy's buffer, dx = [dy | dt]·[Wᵀ | Aᵀ]ᵀ as one GEMM; dB = (s·tᵀ·dy)ᵀ and
+dA = dtᵀ·x through the small-output TN GEMM (bl_gemm_tn_small_bf16: dy / x read once, untransposed).
 """
 from __future__ import annotations
 

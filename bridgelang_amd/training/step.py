@@ -242,6 +242,21 @@ class TrainStep:
         Tn = B * S
         self.T, self.Tp = Tn, (Tn + 63) // 64 * 64
         z = lambda *shape, dtype=torch.bfloat16: torch.zeros(*shape, dtype=dtype, device=dev)
+        # LoRA K-concatenation: the input x of an adapted linear and the gradient dy of its output live in buffers that
+        # are R columns wider than the tensor; t = x·Aᵀ / dt = dy·(sB) land in those columns, so y = [x | t]·[W | sB]ᵀ
+        # and dx = [dy | dt]·[Wᵀ | Aᵀ]ᵀ are single GEMMs over K + R (no separate rank-R update pass over y / dx).
+        self._wide: Dict[int, torch.Tensor] = {}
+        R_ = lambda packed: (lora.get(packed).R if (lora is not None and lora.get(packed) is not None) else 0)
+
+        def za(rows: int, cols: int, extra: int) -> torch.Tensor:
+            if not extra:
+                return z(rows, cols)
+            wide = z(rows, cols + extra)
+            view = wide[:, :cols]
+            self._wide[view.data_ptr()] = wide
+            return view
+        self._za, self._R = za, R_
+        L0 = weights.layers[0]
         # ---- inputs ----
         self.input_ids = z(B, prompt_len, dtype=torch.int64)
         self.key_mask = torch.ones(B, S, dtype=torch.uint8, device=dev)
@@ -251,17 +266,19 @@ class TrainStep:
         from ..engine import OpenVLAEngine
         self._vis = OpenVLAEngine(weights, batch, 1, n_new=1)
         self.pixel_values = self._vis.pixel_values
-        self.feats = self._vis.feats
+        self.feats = self._vis.feats if lora is None else za(B * 256, d.vision_dim, R_(weights.fc1_w))
         # ---- saved activations ----
         Pv = 4 * d.vision_dim
-        self.z1, self.p1, self.z2, self.p2, self.p3 = z(B * 256, Pv), z(B * 256, Pv), z(B * 256, D), z(B * 256, D), z(B * 256, D)
+        self.z1, self.z2, self.p3 = z(B * 256, Pv), z(B * 256, D), z(B * 256, D)
+        self.p1, self.p2 = za(B * 256, Pv, R_(weights.fc2_w)), za(B * 256, D, R_(weights.fc3_w))
         self.x = [z(Tn, D) for _ in range(NL + 1)]            # residual stream entering layer l (x[NL] = final)
         self.xm = [z(Tn, D) for _ in range(NL)]
-        self.h1, self.h2 = [z(Tn, D) for _ in range(NL)], [z(Tn, D) for _ in range(NL)]
-        self.qkv = [z(Tn, 3 * D) for _ in range(NL)]
-        self.ao = [z(Tn, D) for _ in range(NL)]
+        self.h1 = [za(Tn, D, R_(L0.qkv_w)) for _ in range(NL)]
+        self.h2 = [za(Tn, D, R_(L0.gu_w)) for _ in range(NL)]
+        self.qkv = [za(Tn, 3 * D, R_(L0.qkv_w)) for _ in range(NL)]     # same leading dimension as dqkv (shared strides)
+        self.ao = [za(Tn, D, R_(L0.o_w)) for _ in range(NL)]
         self.gu = [z(Tn, 2 * I) for _ in range(NL)]
-        self.act = [z(Tn, I) for _ in range(NL)]
+        self.act = [za(Tn, I, R_(L0.down_w)) for _ in range(NL)]
         pad = (S + 31) // 32 * 32
         self.lse = [z(B * d.llm_heads * pad, dtype=torch.float32) for _ in range(NL)]
         self.delta = z(B * d.llm_heads * pad, dtype=torch.float32)
@@ -271,9 +288,11 @@ class TrainStep:
         self.cos, self.sin = rope_tables(d.head_dim, d.max_pos, d.rope_theta, dev)
         # ---- backward scratch ----
         self.dlogits = z(Tn, V)
-        self.dxa, self.dxb, self.dh, self.dao = z(Tn, D), z(Tn, D), z(Tn, D), z(Tn, D)
-        self.dqkv, self.dgu, self.dact = z(Tn, 3 * D), z(Tn, 2 * I), z(Tn, I)
-        self.dp3, self.dp2, self.dz2, self.dp1, self.dz1 = z(B * 256, D), z(B * 256, D), z(B * 256, D), z(B * 256, Pv), z(B * 256, Pv)
+        rres = max(R_(L0.down_w), R_(L0.o_w))                  # dx / dx2 are the dy of down_proj and o_proj
+        self.dxa, self.dxb, self.dh, self.dao = za(Tn, D, rres), za(Tn, D, rres), z(Tn, D), za(Tn, D, R_(L0.o_w))
+        self.dqkv, self.dgu, self.dact = za(Tn, 3 * D, R_(L0.qkv_w)), za(Tn, 2 * I, R_(L0.gu_w)), z(Tn, I)
+        self.dp3, self.dz2, self.dz1 = za(B * 256, D, R_(weights.fc3_w)), za(B * 256, D, R_(weights.fc2_w)), za(B * 256, Pv, R_(weights.fc1_w))
+        self.dp2, self.dp1 = z(B * 256, D), z(B * 256, Pv)
         nmax = max(V, 3 * D, 2 * I, Pv)
         self.tA, self.tB, self.tBp = z(nmax * self.Tp), z(nmax * self.Tp), z(nmax * self.Tp)
         towers = (weights.dino, weights.siglip) if self.train_vision else ()
@@ -283,17 +302,21 @@ class TrainStep:
         self.col_ws = z(max(((Tn + 31) // 32) * max(Pv, D), 256 * dv_, ((mv + 15) // 16) * dv_ * 4), dtype=torch.float32)
         self._frozen_dw = z(2 * max(D, Pv, dv_), dtype=torch.float32)         # sink for vector grads of frozen tensors
         self._lora_t: Dict[int, torch.Tensor] = {}                            # saved t = x·Aᵀ per adapted linear
+        self._Wext: Dict[int, torch.Tensor] = {}                              # packed [W | s·B]   per adapted linear
+        self._WText: Dict[int, torch.Tensor] = {}                             # packed [Wᵀ | Aᵀ]
+        self._BsT: Dict[int, torch.Tensor] = {}                               # packed (s·B)ᵀ: the dt = dy·(sB) operand
+        self._adapter_ops: List[Op] = []                                      # refresh of the adapter parts (repack plan)
         self.dfeats = z(B * 256, d.vision_dim) if self.train_vision else None
         self.vis = [self._alloc_tower(tw) for tw in towers]
         # ---- transposed weights for dgrad ----
         self._wT: Dict[int, torch.Tensor] = {}
         self.ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+        if lora is not None:
+            self._build_extended_weights()
         self.vision_forward_ops: List[Op] = []
         for tw, sv, col in zip(towers, self.vis, (0, d.dino.dim)):
             self.vision_forward_ops += self._plan_tower_forward(tw, col, sv)
         self.forward_ops = self._plan_forward()
-        tmax = max((t.numel() for t in self._lora_t.values()), default=8)
-        self._lora_tmp, self._lora_tmp2 = z(tmax), z(tmax)
         self.tn_ws = z(8 << 20, dtype=torch.float32) if lora is not None else None
         self._ready: List[Tuple[int, str]] = []      # (number of backward ops enqueued, bucket key complete at that point)
         self.backward_ops = self._plan_backward()
@@ -339,45 +362,65 @@ class TrainStep:
         u = self.store.unit_of_packed(packed)
         return [] if u is None else self._wgrad_into(dy, x, self.store.grad_view(u))
 
-    def _lin(self, x: torch.Tensor, packed: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, **kw) -> List[Op]:
-        """Forward of one nn.Linear: the base GEMM, plus the LoRA branch y += s·(x Aᵀ) Bᵀ when it carries an adapter."""
-        plan = [self._g(x, packed, out, epilogue, **kw)]
-        ad = self.lora.get(packed) if self.lora is not None else None
-        if ad is not None:
-            assert "out_map" not in kw, "row-mapped outputs carry no adapter"
-            t = torch.zeros(x.shape[0], ad.R, dtype=torch.bfloat16, device=self.device)
-            self._lora_t[packed.data_ptr()] = t
-            n = ad.group.n
-            plan += [self._g(x, ad.A_p, t, EPI_NONE),
-                     ops.gemm(t, ad.B_p, out, ops.EPI_BIAS_RES, bias=self.lora.zero_vec[:n], scale=self.lora.scale_vec[:n],
-                              res=out, run=False)]
-        return plan
+    def _build_extended_weights(self) -> None:
+        """LoRA: K-concatenated packed weights [W | s·B] (forward) and [Wᵀ | Aᵀ] (dgrad) per adapted linear. The frozen
+        part is copied once; the adapter columns are (re)written by `_adapter_ops` after every optimizer step."""
+        lora, s = self.lora, self.lora.scaling
+        dev = self.device
+        zb = lambda *shape: torch.zeros(*shape, dtype=torch.bfloat16, device=dev)
+        self._Bs_tmp = zb(max(ad.B.numel() for ad in lora.adapters))
+        for ad in lora.adapters:
+            packed, n, k, R = ad.group.packed, ad.group.n, ad.group.k, ad.R
+            KT, NT = (k + R) // 32, (n + R) // 32
+            We, WTe = zb(n // 16, KT, 64, 8), zb(k // 16, NT, 64, 8)
+            We.view(n // 16, KT, 512)[:, :k // 32].copy_(packed.view(n // 16, k // 32, 512))
+            WTe.view(k // 16, NT, 512)[:, :n // 32].copy_(transposed_pack(packed, n, k).view(k // 16, n // 32, 512))
+            BsT = zb(R // 16, n // 32, 64, 8)
+            key = packed.data_ptr()
+            self._Wext[key], self._WText[key], self._BsT[key] = We, WTe, BsT
+            Bs = self._Bs_tmp[:n * R].view(n, R)
+            self._adapter_ops += [T.scale(ad.B, s, Bs, run=False), T.pack_into(Bs, We, KT, k // 32, run=False),
+                                  T.transpose_pack(Bs, BsT, n, run=False), T.pack(ad.A, ad.A_p, run=False),
+                                  T.transpose_pack_into(ad.A, WTe, R, NT, n // 32, run=False)]
+        ops.run_all(self._adapter_ops)
 
-    def _lin_bwd(self, dy: torch.Tensor, x: torch.Tensor, packed: torch.Tensor, dx: Optional[torch.Tensor]) -> List[Op]:
-        """Backward of one nn.Linear given dy: base wgrad (if trainable), dx = dy·W (if wanted), adapter grads and the
-        adapter's share of dx."""
-        plan = self._wgrad(dy, x, packed)
-        if dx is not None:
-            plan.append(self._dgrad(dy, packed, dx))
+    def _lin(self, x: torch.Tensor, packed: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, **kw) -> List[Op]:
+        """Forward of one nn.Linear. With an adapter: t = x·Aᵀ into the spare columns of x's buffer, then ONE GEMM
+        y = [x | t]·[W | s·B]ᵀ over K + R."""
         ad = self.lora.get(packed) if self.lora is not None else None
         if ad is None:
+            return [self._g(x, packed, out, epilogue, **kw)]
+        K, R = x.shape[1], ad.R
+        wide = self._wide[x.data_ptr()]
+        assert wide.shape[1] >= K + R, "input buffer of an adapted linear lacks the adapter columns"
+        t = wide[:, K:K + R]
+        self._lora_t[packed.data_ptr()] = t
+        return [self._g(x, ad.A_p, t, EPI_NONE), self._g(wide[:, :K + R], self._Wext[packed.data_ptr()], out, epilogue, **kw)]
+
+    def _lin_bwd(self, dy: torch.Tensor, x: torch.Tensor, packed: torch.Tensor, dx: Optional[torch.Tensor]) -> List[Op]:
+        """Backward of one nn.Linear given dy: base wgrad (if trainable) and dx = dy·W (if wanted); with an adapter:
+        dt = dy·(sB) into the spare columns of dy's buffer, dB = (s·tᵀ·dy)ᵀ and dA = dtᵀ·x through the small-output TN
+        GEMM (dy / x read once, untransposed), and dx = [dy | dt]·[Wᵀ | Aᵀ]ᵀ as ONE GEMM."""
+        ad = self.lora.get(packed) if self.lora is not None else None
+        if ad is None:
+            plan = self._wgrad(dy, x, packed)
+            if dx is not None:
+                plan.append(self._dgrad(dy, packed, dx))
             return plan
-        i = ad.index
-        st, s, R = self.store, self.lora.scaling, ad.R
-        t = self._lora_t[packed.data_ptr()]
-        ts = self._lora_tmp[:t.numel()].view(t.shape)
-        dt = self._lora_tmp2[:t.numel()].view(t.shape)
+        i, st, s, R, N = ad.index, self.store, self.lora.scaling, ad.R, dy.shape[1]
+        key = packed.data_ptr()
+        wide = self._wide[dy.data_ptr()]
+        assert wide.shape[1] >= N + R, "gradient buffer of an adapted linear lacks the adapter columns"
+        dt = wide[:, N:N + R]
+        t = self._lora_t[key]
         gB = st.grad_view(f"lora.{i}.B").view(ad.group.n, R)
         gA = st.grad_view(f"lora.{i}.A").view(R, ad.group.k)
-        # adapter gradients read dy / x once, untransposed (bl_gemm_tn_small_bf16): dB = (tsᵀ·dy)ᵀ, dA = dtᵀ·x
-        plan.append(T.scale(t, s, ts, run=False))
-        plan.append(T.gemm_tn_small(ts, dy, gB, True, self.tn_ws, run=False))
+        plan = [self._g(dy, self._BsT[key], dt, EPI_NONE), T.gemm_tn_small(t, dy, gB, True, self.tn_ws, alpha=s, run=False)]
         if len(ad.modules) > 1:
             plan.append(T.lora_block_mask(gB, R // len(ad.modules), len(ad.modules), ad.mode == "interleave", run=False))
-        plan += [self._dgrad(dy, ad.B_p, dt), T.scale(dt, s, dt, run=False)]
         plan.append(T.gemm_tn_small(dt, x, gA, False, self.tn_ws, run=False))
         if dx is not None:
-            plan.append(self._dgrad(dt, ad.A_p, dx, EPI_RES, res=dx))
+            plan.append(self._g(wide[:, :N + R], self._WText[key], dx, EPI_NONE))
         return plan
 
     def _gvec(self, name: str, n: int) -> torch.Tensor:
@@ -401,13 +444,14 @@ class TrainStep:
         plan += lin(self.p2, w.fc3_w, self.p3, EPI_BIAS, bias=w.fc3_b)
         plan += [T.map_rows(self.p3, self.x[0], rows=B * 256, group=256, stride=S, offset=1, scatter=True, run=False),
                  ops.embed_splice(self.input_ids, w.embed, self.x[0].view(B, S, D), d.n_patches, run=False)]
-        st = (S * 3 * D, hd, 3 * D)
+        lq, lo = self.qkv[0].stride(0), self.ao[0].stride(0)
+        st, so = (S * lq, hd, lq), (S * lo, hd, lo)
         for l, lw in enumerate(w.layers):
             x, xm, qkv = self.x[l], self.xm[l], self.qkv[l]
             plan += [ops.rmsnorm(x, lw.ln1, self.h1[l], d.rms_eps, run=False)] + lin(self.h1[l], lw.qkv_w, qkv, EPI_NONE)
             plan += [T.rope(qkv, self.cos, self.sin, B=B, S=S, H=H, head_dim=hd, run=False),
                      T.attention_lse(qkv, qkv[:, D:], qkv[:, 2 * D:], self.ao[l], self.lse[l], B=B, H=H, Sq=S, Skv=S,
-                                     head_dim=hd, q_strides=st, k_strides=st, v_strides=st, o_strides=(S * D, hd, D),
+                                     head_dim=hd, q_strides=st, k_strides=st, v_strides=st, o_strides=so,
                                      causal=True, key_mask=self.key_mask, run=False)]
             plan += lin(self.ao[l], lw.o_w, xm, EPI_RES, res=x)
             plan += [ops.rmsnorm(xm, lw.ln2, self.h2[l], d.rms_eps, run=False)] + lin(self.h2[l], lw.gu_w, self.gu[l], EPI_NONE)
@@ -429,7 +473,9 @@ class TrainStep:
         dx, dx2 = self.dxa, self.dxb
         plan.append(T.rmsnorm_backward(self.x[-1], w.norm, self.dh, dx, self._gvec(f"{lm}.norm.weight", D), self.norm_ws,
                                        d.rms_eps, run=False))
-        strides = (S * 3 * D, hd, 3 * D)
+        lq, lo = self.qkv[0].stride(0), self.ao[0].stride(0)
+        assert self.dqkv.stride(0) == lq and self.dao.stride(0) == lo
+        strides, so = (S * lq, hd, lq), (S * lo, hd, lo)
         stop_layer = self._lowest_needed_layer()
         for l in range(d.llm_layers - 1, stop_layer - 1, -1):
             lw, b = w.layers[l], f"{lm}.layers.{l}"
@@ -443,7 +489,7 @@ class TrainStep:
             plan.append(T.attention_backward(qkv, qkv[:, D:], qkv[:, 2 * D:], self.ao[l], self.dao, self.lse[l], self.delta,
                                              dq, dq[:, D:], dq[:, 2 * D:], B=B, H=H, Sq=S, Skv=S, head_dim=hd,
                                              q_strides=strides, k_strides=strides, v_strides=strides,
-                                             o_strides=(S * D, hd, D), causal=True, key_mask=self.key_mask, run=False))
+                                             o_strides=so, causal=True, key_mask=self.key_mask, run=False))
             plan.append(T.rope_backward(dq, self.cos, self.sin, B=B, S=S, H=H, head_dim=hd, run=False))
             plan += lb(dq, self.h1[l], lw.qkv_w, self.dh)
             self._ready.append((len(plan), f"llm.layer{l:02d}"))
@@ -479,13 +525,16 @@ class TrainStep:
         z = lambda *shape, dtype=torch.bfloat16: torch.zeros(*shape, dtype=dtype, device=self.device)
         pad = (t.tokens + 31) // 32 * 32
         ls = t.layerscale
+        za, R_, b0 = self._za, self._R, tw.blocks[0]
+        rr = max(R_(b0.fc2_w), R_(b0.proj_w))                  # dx / dx2 / du are the dy of fc2 and proj
         return dict(
-            x=[z(M, Dm) for _ in range(n + 1)], h1=[z(M, Dm) for _ in range(n)], qkv=[z(M, 3 * Dm) for _ in range(n)],
-            ao=[z(M, Dm) for _ in range(n)], lse=[z(B * t.heads * pad, dtype=torch.float32) for _ in range(n)],
-            xm=[z(M, Dm) for _ in range(n)], h2=[z(M, Dm) for _ in range(n)], zz=[z(M, Hp) for _ in range(n)],
-            f=[z(M, Hp) for _ in range(n)], u1=[z(M, Dm) if ls else None for _ in range(n)],
+            x=[z(M, Dm) for _ in range(n + 1)], h1=[za(M, Dm, R_(b0.qkv_w)) for _ in range(n)], qkv=[za(M, 3 * Dm, R_(b0.qkv_w)) for _ in range(n)],
+            ao=[za(M, Dm, R_(b0.proj_w)) for _ in range(n)], lse=[z(B * t.heads * pad, dtype=torch.float32) for _ in range(n)],
+            xm=[z(M, Dm) for _ in range(n)], h2=[za(M, Dm, R_(b0.fc1_w)) for _ in range(n)], zz=[z(M, Hp) for _ in range(n)],
+            f=[za(M, Hp, R_(b0.fc2_w)) for _ in range(n)], u1=[z(M, Dm) if ls else None for _ in range(n)],
             u2=[z(M, Dm) if ls else None for _ in range(n)], delta=z(B * t.heads * pad, dtype=torch.float32),
-            dxa=z(M, Dm), dxb=z(M, Dm), dh=z(M, Dm), du=z(M, Dm), dao=z(M, Dm), dqkv=z(M, 3 * Dm), df=z(M, Hp), dz=z(M, Hp),
+            dxa=za(M, Dm, rr), dxb=za(M, Dm, rr), dh=z(M, Dm), du=za(M, Dm, rr), dao=za(M, Dm, R_(b0.proj_w)), dqkv=za(M, 3 * Dm, R_(b0.qkv_w)),
+            df=z(M, Hp), dz=za(M, Hp, R_(b0.fc1_w)),
             dpe=z(B * 256, Dm), tok=z(max(t.n_prefix, 1) * Dm, dtype=torch.float32))
 
     def _plan_tower_forward(self, tw, feat_col: int, sv: dict) -> List[Op]:
@@ -499,14 +548,15 @@ class TrainStep:
             plan.append(ops.write_prefix_tokens(tw.prefix, x0, B, Tk, run=False))
         plan.append(g(col, tw.patch_w, x0, ops.EPI_BIAS_RES, bias=tw.patch_b, res=tw.pos, res_row_mod=256,
                       out_map=(256, Tk, t.n_prefix)))
-        st = (Tk * 3 * Dm, hd, 3 * Dm)
+        lq, lo = sv["qkv"][0].stride(0), sv["ao"][0].stride(0)
+        st, so = (Tk * lq, hd, lq), (Tk * lo, hd, lo)
         for i, b in enumerate(tw.blocks):
             x, xm, qkv = sv["x"][i], sv["xm"][i], sv["qkv"][i]
             plan += [ops.layernorm(x, b.norm1_w, b.norm1_b, sv["h1"][i], eps, run=False)]
             plan += self._lin(sv["h1"][i], b.qkv_w, qkv, EPI_BIAS, bias=b.qkv_b)
             plan += [T.attention_lse(qkv, qkv[:, Dm:], qkv[:, 2 * Dm:], sv["ao"][i], sv["lse"][i], B=B, H=t.heads, Sq=Tk,
                                      Skv=Tk, head_dim=hd, q_strides=st, k_strides=st, v_strides=st,
-                                     o_strides=(Tk * Dm, hd, Dm), causal=False, run=False)]
+                                     o_strides=so, causal=False, run=False)]
             if b.ls1 is not None:
                 plan += self._lin(sv["ao"][i], b.proj_w, sv["u1"][i], EPI_BIAS, bias=b.proj_b)
                 plan.append(T.scale_residual(sv["u1"][i], b.ls1, x, xm, run=False))
@@ -535,10 +585,12 @@ class TrainStep:
         gb = lambda name: st.grad_view(name) if st.trainable(name) else self._frozen_dw[Dm:2 * Dm]   # 2nd sink: LN dw + db
         lb = self._lin_bwd
         dx, dx2 = sv["dxa"], sv["dxb"]
-        plan: List[Op] = [T.fill_zero(dx, run=False),
+        plan: List[Op] = [T.fill_zero(self._wide.get(dx.data_ptr(), dx), run=False),
                           T.map_rows(self.dfeats[:, feat_col:feat_col + Dm], dx, rows=B * 256, group=256, stride=Tk,
                                      offset=t.n_prefix, scatter=True, run=False)]
-        strides = (Tk * 3 * Dm, hd, 3 * Dm)
+        lq, lo = sv["qkv"][0].stride(0), sv["ao"][0].stride(0)
+        assert sv["dqkv"].stride(0) == lq and sv["dao"].stride(0) == lo
+        strides, so = (Tk * lq, hd, lq), (Tk * lo, hd, lo)
         for i in range(t.n_run - 1, -1, -1):
             b, bn = tw.blocks[i], f"{p}.blocks.{i}"
             dbr = dx
@@ -562,7 +614,7 @@ class TrainStep:
             plan.append(T.attention_backward(qkv, qkv[:, Dm:], qkv[:, 2 * Dm:], sv["ao"][i], sv["dao"], sv["lse"][i], sv["delta"],
                                              dq, dq[:, Dm:], dq[:, 2 * Dm:], B=B, H=t.heads, Sq=Tk, Skv=Tk, head_dim=hd,
                                              q_strides=strides, k_strides=strides, v_strides=strides,
-                                             o_strides=(Tk * Dm, hd, Dm), causal=False, run=False))
+                                             o_strides=so, causal=False, run=False))
             plan += self._bias_grad(dq, f"{bn}.attn.qkv.bias")
             plan += lb(dq, sv["h1"][i], b.qkv_w, sv["dh"])
             self._ready.append((base + len(plan), f"vision.{tower_key}.block{i:02d}"))
@@ -609,13 +661,7 @@ class TrainStep:
             key = u.group.packed.data_ptr()
             if key in self._wT:                                   # only weights that a dgrad GEMM actually reads
                 plan.append(T.transpose_pack(rm, self._wT[key], n, run=False))
-        if self.lora is not None:
-            for ad in self.lora.adapters:
-                for rm, pk in ((ad.A, ad.A_p), (ad.B, ad.B_p)):
-                    plan.append(T.pack(rm, pk, run=False))
-                    if pk.data_ptr() in self._wT:
-                        n, k = rm.shape
-                        plan.append(T.transpose_pack(rm, self._wT[pk.data_ptr()], n, run=False))
+        plan += self._adapter_ops                                 # LoRA: adapter columns of the K-concatenated weights
         return plan
 
     # ---- running ------------------------------------------------------------------------------------------------

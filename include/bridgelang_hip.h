@@ -140,7 +140,7 @@ int bl_attention_backward_bf16(const bl_attn_desc* d, const bl_bf16* dout, const
 int bl_attention_decode_bf16(const bl_attn_desc* d, void* stream);
 
 /* Training forward: rotate q and k of the fused qkv rows IN PLACE (same arithmetic as bl_rope_kvcache_bf16, no cache). */
-int bl_rope_bf16(bl_bf16* qkv, int32_t B, int32_t S, int32_t H, int32_t head_dim, const bl_bf16* cos_tab,
+int bl_rope_bf16(bl_bf16* qkv, int64_t ld, int32_t B, int32_t S, int32_t H, int32_t head_dim, const bl_bf16* cos_tab,
                  const bl_bf16* sin_tab, int32_t pos0, void* stream);
 
 /* Decode attention with the rotary embedding and the KV-cache append of the NEW token fused in: q / k_new / v_new are
@@ -197,11 +197,13 @@ int bl_colsum_bf16(const bl_bf16* a, int64_t lda, int32_t rows, int32_t cols, fl
 int bl_swiglu_bf16(const bl_bf16* gu, int64_t ldg, bl_bf16* act, int64_t lda, int64_t rows, int32_t inter, void* stream);
 int bl_swiglu_backward_bf16(const bl_bf16* gu, int64_t ldg, const bl_bf16* dact, int64_t ldd, bl_bf16* dgu, int64_t ldo,
                             int64_t rows, int32_t inter, void* stream);
-/* exact-erf GELU and its derivative on flat tensors (projector: nn_utils.py:42-48). */
-int bl_gelu_bf16(const bl_bf16* x, bl_bf16* y, int64_t n, void* stream);
-int bl_gelu_backward_bf16(const bl_bf16* x, const bl_bf16* dy, bl_bf16* dx, int64_t n, void* stream);
+/* exact-erf GELU and its derivative on [rows, cols] matrices with leading dimensions (projector: nn_utils.py:42-48;
+ * timm Mlp). */
+int bl_gelu_bf16(const bl_bf16* x, int64_t ldx, bl_bf16* y, int64_t ldy, int64_t rows, int32_t cols, void* stream);
+int bl_gelu_backward_bf16(const bl_bf16* x, int64_t ldx, const bl_bf16* dy, int64_t lddy, bl_bf16* dx, int64_t lddx, int64_t rows,
+                          int32_t cols, void* stream);
 /* Transposed rotation on the q and k thirds of dqkv [B*S, 3*H*hd], in place. */
-int bl_rope_backward_bf16(bl_bf16* dqkv, int32_t B, int32_t S, int32_t H, int32_t hd, const bl_bf16* cos_tab,
+int bl_rope_backward_bf16(bl_bf16* dqkv, int64_t ld, int32_t B, int32_t S, int32_t H, int32_t hd, const bl_bf16* cos_tab,
                           const bl_bf16* sin_tab, int32_t pos0, void* stream);
 /* out[c][r] = in[r][c], rows padded with zeros to rows_pad (the reduction dim of a wgrad GEMM must be a multiple of 64). */
 int bl_transpose_pad_bf16(const bl_bf16* in, int64_t ldi, int32_t rows, int32_t cols, bl_bf16* out, int64_t ldo,
@@ -210,6 +212,13 @@ int bl_transpose_pad_bf16(const bl_bf16* in, int64_t ldi, int32_t rows, int32_t 
  * matrix (cols % 64 == 0, rows_pad % 32 == 0): the packed operand of a wgrad GEMM in one pass. */
 int bl_transpose_pack_bf16(const bl_bf16* in, int64_t ld_in, int32_t rows, int32_t cols, bl_bf16* out_packed,
                            int32_t rows_pad, void* stream);
+/* The two packers with a destination window: the source becomes k-blocks [kb_offset, kb_offset + K/32) of every n-tile
+ * of a packed matrix that has kt_total k-blocks per n-tile — the adapter columns of a K-concatenated LoRA weight
+ * [W | s·B] / [Wᵀ | Aᵀ] (training/step.py), refreshed after every optimizer step without touching the frozen part. */
+int bl_pack_weight_into_bf16(const bl_bf16* w, int64_t ldw, int64_t N, int64_t K, bl_bf16* out, int64_t kt_total,
+                             int64_t kb_offset, void* stream);
+int bl_transpose_pack_into_bf16(const bl_bf16* in, int64_t ld_in, int32_t rows, int32_t cols, bl_bf16* out_packed,
+                                int32_t rows_pad, int64_t kt_total, int64_t kb_offset, void* stream);
 /* Global gradient norm (fsdp.py:268-270): per-tensor partial sums of squares, then norm and clip coefficient
  * out_norm_coef = {||g||, min(1, max_norm / (||g|| + 1e-6))} (torch.nn.utils.clip_grad_norm_). */
 int bl_sumsq_partial_f32(const float* g, int64_t n, float* partial, int32_t nblocks, void* stream);
@@ -228,10 +237,10 @@ int bl_layerscale_backward_bf16(const bl_bf16* dy, int64_t lddy, const bl_bf16* 
                                 int32_t rows, int32_t cols, void* stream);
 /* Small-output TN GEMM for the LoRA adapter gradients (dA = dt^T x, dB = (ts^T dy)^T; finetune.py:174-189 → PEFT's
  * autograd): C = P^T Q with P [T, R] (R = 64, 128 or 192), Q [T, N] (N % 64 == 0), both row-major bf16, reduction over
- * the T rows, fp32 output — C [R, N] (transpose_out = 0) or C [N, R] (transpose_out = 1), dense (ldc = N or R). Reads Q
+ * the T rows, fp32 output scaled by alpha — C [R, N] (transpose_out = 0) or C [N, R] (transpose_out = 1), dense (ldc = N or R). Reads Q
  * once, untransposed. partial_ws (optional, fp32) lets small-N calls split T across workgroups deterministically. */
 int bl_gemm_tn_small_bf16(const bl_bf16* P, int64_t ldp, const bl_bf16* Q, int64_t ldq, int32_t T, int32_t R, int32_t N,
-                          float* C, int64_t ldc, int32_t transpose_out, float* partial_ws, int64_t partial_ws_floats,
+                          float* C, int64_t ldc, int32_t transpose_out, float alpha, float* partial_ws, int64_t partial_ws_floats,
                           void* stream);
 /* LoRA (vla-scripts/finetune.py:174-189): out = bf16(s * x) for the small rank-space tensors; gradient mask that keeps
  * the off-block entries of a fused adapter's B [n_rows, members * rp] at zero (row n belongs to member n / (n_rows /

@@ -119,3 +119,39 @@ def test_lora_gradients_and_adamw_step(dev):
                        dims, ids, mask, labels, pv)
     print(f"[lora] after one step: loss {loss2:.5f} vs oracle {ref2.item():.5f}")
     assert abs(loss2 - ref2.item()) <= 3e-3 * abs(ref2.item()) and loss2 < loss
+
+
+def test_lora_three_step_loss_curve_vs_oracle(dev):
+    """Three optimisation steps from the PEFT initialisation (A gaussian, B = 0): the loss curve must follow the CPU
+    restatement trained with torch.optim.AdamW on bf16-rounded adapter copies (SURVEY §8d cfg 3/4: loss-curve parity)."""
+    from bridgelang_amd.training.lora import LoraAdapters
+    from bridgelang_amd.training.step import TrainStep
+    from bridgelang_amd.weights import allocate, tiny_dims
+    dims = tiny_dims()
+    w = allocate(dims, dev).fill_synthetic(seed=3)
+    sd = {k: v.float().cpu() for k, v in w.state_dict().items()}
+    lora = LoraAdapters(w, r=32, seed=5)
+    init = lora.state_dict()
+    assert all(v.abs().sum() == 0 for k, v in init.items() if "lora_B" in k)
+    mods = [m for ad in lora.adapters for m in ad.modules]
+    B, L, lr = 3, 20, 2e-3
+    ts = TrainStep(w, "lora", B, L, lora=lora, max_grad_norm=float("inf"), weight_decay=0.01)
+    params = {k: v.clone().requires_grad_(True) for k, v in init.items()}
+    opt = torch.optim.AdamW(list(params.values()), lr=lr)
+    got, want = [], []
+    for step in range(3):
+        ids, mask, labels, pv = make_batch(dims, B, L, seed=40 + step)
+        ts.set_batch(ids, mask, pv, labels)
+        loss, _ = ts.step(lr)
+        got.append(loss.item())
+        live = {k: v.detach().to(torch.bfloat16).float().requires_grad_(True) for k, v in params.items()}
+        ref = oracle_loss(effective_sd(sd, live, lora.scaling, mods), dims, ids, mask, labels, pv)
+        ref.backward()
+        for k in params:
+            params[k].grad = live[k].grad
+        opt.step()
+        opt.zero_grad()
+        want.append(ref.item())
+    print("lora loss curve", [round(x, 4) for x in got], "oracle", [round(x, 4) for x in want])
+    assert all(abs(a - b) <= 5e-3 * abs(b) for a, b in zip(got, want))
+    assert got[2] < got[0] - 0.02

@@ -270,3 +270,19 @@ def test_gemm_tn_small(dev, Tn, R, N, trans):
         C = torch.full(ref.shape, float("nan"), device=dev)
         T.gemm_tn_small(dv(P_, dev), dv(Q_, dev), C, trans, ws)
         assert torch.allclose(C.cpu(), ref, rtol=1e-4, atol=1e-4 * ref.abs().max().item()), (C.cpu() - ref).abs().max()
+
+
+def test_pack_into_windows(dev):
+    """The packers with a destination window: [W | B] and [Wt | At] assembled from parts equal packing the concatenation."""
+    from bridgelang_amd import ops, train_ops as T
+    n, k, R = 192, 256, 64
+    w, b, a = rand_bf16((n, k), 1), rand_bf16((n, R), 2), rand_bf16((R, k), 3)
+    KT, NT = (k + R) // 32, (n + R) // 32
+    We = torch.zeros(n // 16, KT, 64, 8, dtype=torch.bfloat16, device=dev)
+    T.pack_into(dv(w, dev), We, KT, 0)
+    T.pack_into(dv(b, dev), We, KT, k // 32)
+    assert torch.equal(We, ops.pack_weight(dv(torch.cat([w, b], 1), dev)))
+    WTe = torch.zeros(k // 16, NT, 64, 8, dtype=torch.bfloat16, device=dev)
+    T.transpose_pack_into(dv(w, dev), WTe, n, NT, 0)
+    T.transpose_pack_into(dv(a, dev), WTe, R, NT, n // 32)
+    assert torch.equal(WTe, ops.pack_weight(dv(torch.cat([w.t(), a.t()], 1).contiguous(), dev)))
