@@ -1,0 +1,97 @@
+"""Full-size (openvla-7b, batch 16, S = 288) check of the training path through a size-independent property: the
+directional derivative. With LoRA's B = 0 initialisation a step B ← −ε·g_B/‖g_B‖ is exactly representable, so
+loss(B) − loss(0) must equal −ε‖g_B‖ to first order, and g_A must be exactly zero. This validates, at 7B, the whole
+forward (K-concatenated adapters), the hand-written backward down to the vision towers, and the adapter gradients —
+none of which the CPU oracle can reach at this size."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lora_directional_derivative_full_size(dev):
+    from bridgelang_amd import ops
+    from bridgelang_amd.training.lora import LoraAdapters
+    from bridgelang_amd.training.step import TrainStep
+    from bridgelang_amd.weights import allocate, openvla_7b_dims
+    B, L = 16, 32
+    w = allocate(openvla_7b_dims(), dev).fill_synthetic(seed=0)
+    lora = LoraAdapters(w, r=32)
+    ts = TrainStep(w, "lora", B, L, lora=lora, max_grad_norm=float("inf"), weight_decay=0.01)
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(3, 31000, (B, L), generator=g)
+    ids[:, 0] = 1
+    ids[:, -8:-1] = torch.randint(31744, 32000, (B, 7), generator=g)
+    ids[:, -1] = 2
+    labels = torch.full((B, L), -100)
+    labels[:, -8:] = ids[:, -8:]
+    pv = torch.randn(B, 6, 224, 224, generator=g).to(torch.bfloat16)
+    ts.set_batch(ids, None, pv, labels)
+    loss0 = ts.forward().item()
+    ts.backward()
+    st = ts.store
+    n = len(lora.adapters)
+    gA = torch.stack([st.grad_view(f"lora.{i}.A").abs().max() for i in range(n)]).max().item()
+    nB = torch.stack([st.grad_view(f"lora.{i}.B").double().pow(2).sum() for i in range(n)]).sum().sqrt().item()
+    assert gA == 0.0, "dA must vanish while B = 0"
+    assert nB > 0 and all(st.grad_view(f"lora.{i}.B").abs().max() > 0 for i in range(n)), "every adapter receives a gradient"
+    for target in (0.1, 0.3):
+        eps = target / nB
+        for i, ad in enumerate(lora.adapters):
+            ad.B.copy_((-(eps / nB) * st.grad_view(f"lora.{i}.B").view(ad.B.shape)).to(torch.bfloat16))
+        ops.run_all(ts._adapter_ops)
+        d = ts.forward().item() - loss0
+        print(f"directional derivative: predicted {-target:.4f}, measured {d:.4f}")
+        assert abs(d + target) <= 0.08 * target + 0.004, (target, d)
+    del ts, lora, w
+    torch.cuda.empty_cache()
+
+
+def test_full_finetune_wgrad_consistent_with_lora_full_size(dev):
+    """At B = 0 the adapter gradient of a linear is a projection of its full weight gradient: dB = s·dyᵀ·(x Aᵀ) =
+    s·G_W·Aᵀ. The full fine-tuning step (stage vla-train: transposes + NT wgrad GEMMs, fp32 accumulation) and the LoRA
+    step (small-output TN GEMMs) compute the two sides through disjoint kernels; with the LoRA side pinned by the
+    directional derivative above, agreement validates the 7B full-fine-tuning gradients of the sampled linears."""
+    from bridgelang_amd.training.lora import LoraAdapters
+    from bridgelang_amd.training.step import TrainStep
+    from bridgelang_amd.weights import allocate, openvla_7b_dims
+    B, L = 16, 32
+    dims = openvla_7b_dims()
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(3, 31000, (B, L), generator=g)
+    ids[:, 0] = 1
+    ids[:, -8:-1] = torch.randint(31744, 32000, (B, 7), generator=g)
+    ids[:, -1] = 2
+    labels = torch.full((B, L), -100)
+    labels[:, -8:] = ids[:, -8:]
+    pv = torch.randn(B, 6, 224, 224, generator=g).to(torch.bfloat16)
+    names = ["language_model.model.layers.31.mlp.down_proj.weight", "language_model.model.layers.16.self_attn.o_proj.weight",
+             "language_model.model.layers.0.self_attn.k_proj.weight", "language_model.model.layers.7.mlp.up_proj.weight",
+             "projector.fc2.weight"]
+    w = allocate(dims, dev).fill_synthetic(seed=0)
+    ts = TrainStep(w, "vla-train", B, L)
+    ts.set_batch(ids, None, pv, labels)
+    loss_full = ts.forward().item()
+    ts.backward()
+    GW = {n: ts.store.named_grad(n).float().clone() for n in names}
+    del ts
+    torch.cuda.empty_cache()
+    lora = LoraAdapters(w, r=32, seed=3)
+    tl = TrainStep(w, "lora", B, L, lora=lora, max_grad_norm=float("inf"))
+    tl.set_batch(ids, None, pv, labels)
+    loss_lora = tl.forward().item()
+    tl.backward()
+    assert abs(loss_full - loss_lora) <= 2e-3 * loss_full          # B = 0: same function
+    grads = lora.state_dict({u.key: tl.store.grad[u.offset:u.offset + u.numel] for u in tl.store.units})
+    A = lora.state_dict()
+    for n in names:
+        mod = n[:-len(".weight")]
+        a = A[f"base_model.model.{mod}.lora_A.weight"].to(dev)                       # [r, in]
+        want = lora.scaling * (GW[n] @ a.t())                                          # [out, r]
+        got = grads[f"base_model.model.{mod}.lora_B.weight"].to(dev)
+        c = torch.nn.functional.cosine_similarity(got.flatten().double(), want.flatten().double(), dim=0).item()
+        rel = ((got - want).norm() / want.norm()).item()
+        print(f"{mod}: cosine {c:.5f}, rel. diff {rel:.4f}")
+        assert c > 0.995 and rel < 0.1, (n, c, rel)
+    del tl, lora, w
+    torch.cuda.empty_cache()
