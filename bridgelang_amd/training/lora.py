@@ -83,8 +83,6 @@ class LoraAdapters:
             ad.index = len(self.adapters)
             self.adapters.append(ad)
             self.by_packed[g.packed.data_ptr()] = ad
-        self.scale_vec = torch.full((max(g.n for g in w.groups),), self.scaling, dtype=torch.bfloat16, device=dev)
-        self.zero_vec = torch.zeros_like(self.scale_vec)
         self.init_gaussian(seed)
 
     def get(self, packed: torch.Tensor) -> Optional[Adapter]:
