@@ -227,6 +227,34 @@ __global__ void pack_weight_kernel(const uint16_t* src, long ld, long n, long k,
   }
 }
 
+// ---- frames already at the model resolution: uint8 HWC → the two normalised, channel-stacked bf16 images ----
+// out[b][c][y][x] = bf16(((u8 / 255) − mean0[c]) / std0[c]) for c < 3 and with (mean1, std1) for c ≥ 3: to_tensor + normalize of
+// PrismaticImageProcessor.apply_transform (processing_prismatic.py:128-145) in the same fp32 operation order, then the
+// `.to(torch.bfloat16)` of the call sites. One thread = 8 consecutive pixels of a row (24 input bytes, 6 × 16-byte stores).
+__global__ void preprocess_u8_kernel(const uint8_t* frames, int B, int hw, uint16_t* out, const float* mean_std) {
+  const long total = (long)B * (hw >> 3);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / (hw >> 3);
+    const int p0 = (int)(i - b * (hw >> 3)) * 8;
+    const uint8_t* src = frames + (b * hw + p0) * 3;
+    uint8_t px[24];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *(uint32_t*)(px + 4 * j) = *(const uint32_t*)(src + 4 * j);
+#pragma unroll
+    for (int c6 = 0; c6 < 6; ++c6) {
+      const int c = c6 % 3;
+      const float mean = mean_std[c6], sd = mean_std[6 + c6];
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)px[e * 3 + c], 255.0f), mean), sd);
+      u32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+      *(u32x4_t*)(out + ((b * 6 + c6) * hw + p0)) = o;
+    }
+  }
+}
+
 inline int grid_for(long total, int block) {
   long g = (total + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));   // cap at 256 CUs × 8 and grid-stride the rest
@@ -317,6 +345,18 @@ extern "C" int bl_argmax_f32(const float* logits, int64_t ld, int32_t rows, int3
   if (rows <= 0 || n <= 0 || (n % 4) || (ld % 4)) return BL_E_SHAPE;
   if (!bl_aligned16(logits)) return BL_E_ALIGN;
   hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, n, out);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_preprocess_u8_bf16(const uint8_t* frames, int32_t B, int32_t height, int32_t width, const float* mean_std,
+                                     bl_bf16* out, void* stream) {
+  if (!frames || !mean_std || !out) return BL_E_ARG;
+  const long hw = (long)height * width;
+  if (B <= 0 || height <= 0 || width <= 0 || (hw % 8)) return BL_E_SHAPE;
+  if ((((uintptr_t)frames) & 3) || !bl_aligned16(out)) return BL_E_ALIGN;
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for((long)B * (hw / 8), 256)), dim3(256), 0, (hipStream_t)stream, frames,
+                     B, (int)hw, out, mean_std);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

@@ -46,6 +46,23 @@ class PrismaticImageProcessor:
             planes.append(t.sub_(m).div_(s))                                          # TVF.normalize
         return torch.vstack(planes)
 
+    def preprocess_frames_gpu(self, frames: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """uint8 frames [B, 224, 224, 3] resident on the GPU (already at the model resolution: the resize is then the
+        identity) → pixel_values [B, 6, 224, 224] bf16, bit-identical to `apply_transform(...).to(torch.bfloat16)`.
+        One HBM-bound kernel (bl_preprocess_u8_bf16); frames of any other size go through `preprocess` on the host."""
+        from ... import ops
+        (_, h, w) = self.input_sizes[0]
+        if frames.shape[1:3] != (h, w) or len(self.means) != 2:
+            raise ValueError(f"preprocess_frames_gpu needs frames at the model resolution {h}x{w} and the fused backbone")
+        key = frames.device
+        if getattr(self, "_mean_std", None) is None or self._mean_std.device != key:
+            flat = [v for m in self.means for v in m] + [v for s_ in self.stds for v in s_]
+            self._mean_std = torch.tensor(flat, dtype=torch.float32, device=key)
+        if out is None:
+            out = torch.empty(frames.shape[0], 6, h, w, dtype=torch.bfloat16, device=key)
+        ops.preprocess_u8(frames, self._mean_std, out)
+        return out
+
     def preprocess(self, images: Union[Image.Image, List[Image.Image]], return_tensors: Optional[str] = None,
                    **_: Any) -> Dict[str, Any]:
         if not isinstance(images, list):

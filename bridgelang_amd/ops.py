@@ -17,7 +17,7 @@ from ._lib import (AttnDesc, GemmDesc, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EP
                    EPI_RES, EPI_SWIGLU)
 
 __all__ = ["Op", "gemm", "pack_weight", "unpack_weight", "cross_entropy", "layernorm", "rmsnorm", "attention", "attention_decode", "attention_decode_rope", "skinny_supported", "rope_kvcache", "embed_splice",
-           "argmax", "im2col_patch14", "write_prefix_tokens", "fill_synth", "run_all",
+           "argmax", "im2col_patch14", "preprocess_u8", "write_prefix_tokens", "fill_synth", "run_all",
            "EPI_NONE", "EPI_BIAS", "EPI_BIAS_GELU", "EPI_BIAS_RES", "EPI_RES", "EPI_SWIGLU", "EPI_F32", "EPI_F32_BF16R"]
 
 
@@ -330,6 +330,21 @@ def write_prefix_tokens(prefix: torch.Tensor, x: torch.Tensor, B: int, T: int, r
     n_prefix, dim = prefix.shape
     op = Op("bl_write_prefix_tokens_bf16", lib.bl_write_prefix_tokens_bf16,
             (_bf16(prefix, "prefix").data_ptr(), n_prefix, dim, _bf16(x, "x").data_ptr(), B, T), (prefix, x))
+    if run:
+        op.run()
+    return op
+
+
+def preprocess_u8(frames: torch.Tensor, mean_std: torch.Tensor, out: torch.Tensor, run: bool = True) -> Op:
+    """uint8 frames [B, H, W, 3] already at the model resolution → pixel_values [B, 6, H, W] bf16 (bl_preprocess_u8_bf16)."""
+    lib = _lib.load()
+    if frames.dtype != torch.uint8 or not frames.is_cuda or not frames.is_contiguous() or frames.dim() != 4 or frames.shape[-1] != 3:
+        raise TypeError("preprocess_u8: frames must be a contiguous CUDA/HIP uint8 tensor [B, H, W, 3]")
+    B, H, W, _ = frames.shape
+    if tuple(out.shape) != (B, 6, H, W) or not out.is_contiguous() or mean_std.dtype != torch.float32 or mean_std.numel() != 12:
+        raise ValueError("preprocess_u8: out must be contiguous [B, 6, H, W] bf16, mean_std 12 floats")
+    op = Op("bl_preprocess_u8_bf16", lib.bl_preprocess_u8_bf16, (frames.data_ptr(), B, H, W, mean_std.data_ptr(), _bf16(out, "out").data_ptr()),
+            (frames, mean_std, out), nbytes=B * H * W * (3 + 12.0))
     if run:
         op.run()
     return op

@@ -260,6 +260,12 @@ int bl_embed_backward_bf16(const int64_t* ids, int32_t B, int32_t L, const bl_bf
                            float* dw, void* stream);
 
 /* ---- vision glue ------------------------------------------------------------------------------------------- */
+/* Frames already at the model resolution: uint8 [B, H, W, 3] → pixel_values [B, 6, H, W] bf16 = to_tensor + the two
+ * normalisations of PrismaticImageProcessor.apply_transform (processing_prismatic.py:128-145; DINOv2 ImageNet mean/std,
+ * SigLIP 0.5/0.5) in its fp32 operation order, channel-stacked, rounded to bf16 as the call sites do
+ * (`.to(torch.bfloat16)`). mean_std: 12 device floats = mean[6] | std[6]. H*W % 8 == 0. (Resizing stays on the host.) */
+int bl_preprocess_u8_bf16(const uint8_t* frames, int32_t B, int32_t height, int32_t width, const float* mean_std, bl_bf16* out,
+                          void* stream);
 /* pixel_values [B, 6, 224, 224] bf16 (processing_prismatic.py:128-145 layout) → 14x14 patch rows for one tower:
  * out[b*256 + py*16 + px, c*196 + i*14 + j] = pixel_values[b, chan0 + c, py*14 + i, px*14 + j]; columns 588..ld-1
  * are zeroed (K padded to a multiple of 64 for the patch-embed GEMM; timm PatchEmbed conv flattening order). */

@@ -349,3 +349,17 @@ def test_embed_splice_argmax_im2col_prefix(dev):
     ops.write_prefix_tokens(dv(pre, dev), x, B, 21)
     got = x.cpu().float().view(B, 21, dim)
     assert torch.equal(got[:, :5], pre.expand(B, 5, dim)) and (got[:, 5:] == 0).all()
+
+
+def test_preprocess_uint8_frames_bit_exact(dev):
+    """GPU to_tensor + dual normalise + channel stack of frames at the model resolution ≡ the host image processor."""
+    from PIL import Image
+    from bridgelang_amd.extern.hf.processing_prismatic import PrismaticImageProcessor
+    rs = np.random.RandomState(0)
+    frames = rs.randint(0, 256, (3, 224, 224, 3), dtype=np.uint8)
+    frames[0, :2] = 0
+    frames[1, :2] = 255
+    ip = PrismaticImageProcessor()
+    ref = torch.stack([ip.apply_transform(Image.fromarray(f)) for f in frames]).to(torch.bfloat16)
+    got = ip.preprocess_frames_gpu(torch.from_numpy(frames).to(dev))
+    assert got.shape == (3, 6, 224, 224) and torch.equal(got.cpu(), ref)
