@@ -354,6 +354,27 @@ __global__ void lora_block_mask_kernel(float* g, int n_rows, int R, int rp, int 
   }
 }
 
+// ---- wire format of the gradient reduce-scatter (fsdp.py:139-147 reduce_dtype = bf16): fp32 ↔ bf16 casts ----
+__global__ void cast_f32_bf16_kernel(const float* src, uint16_t* dst, long n) {
+  const long n8 = n >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const f32x4_t a = *(const f32x4_t*)(src + i * 8), b = *(const f32x4_t*)(src + i * 8 + 4);
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    *(u32x4_t*)(dst + i * 8) = pack8(v);
+  }
+  for (long i = (n8 << 3) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = f2bf(src[i]);
+}
+__global__ void cast_bf16_f32_kernel(const uint16_t* src, float* dst, long n) {
+  const long n8 = n >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    unpack8(*(const u32x4_t*)(src + i * 8), v);
+    *(f32x4_t*)(dst + i * 8) = (f32x4_t){v[0], v[1], v[2], v[3]};
+    *(f32x4_t*)(dst + i * 8 + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+  }
+  for (long i = (n8 << 3) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = bf2f(src[i]);
+}
+
 // ---- row gather / scatter: out row r ↔ src row (r / group) * stride + offset + r % group (the projector's 256 patch rows
 //      inside the [B, S, D] embedding buffer) ----
 __global__ void map_rows_kernel(const uint16_t* src, long lds_, uint16_t* dst, long ldd, long rows, int cols, int group,
@@ -743,6 +764,23 @@ extern "C" int bl_lora_block_mask_f32(float* g, int32_t n_rows, int32_t R, int32
   if (n_rows <= 0 || R <= 0 || rp <= 0 || members <= 0 || R != rp * members || (n_rows % members)) return BL_E_SHAPE;
   hipLaunchKernelGGL(lora_block_mask_kernel, dim3(grid_for((long)n_rows * R, 256)), dim3(256), 0, (hipStream_t)stream, g,
                      n_rows, R, rp, members, interleave);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_cast_f32_bf16(const float* src, bl_bf16* dst, int64_t n, void* stream) {
+  if (!src || !dst) return BL_E_ARG;
+  if (n <= 0) return BL_E_SHAPE;
+  if (!bl_aligned16(src) || !bl_aligned16(dst)) return BL_E_ALIGN;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, (long)n);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+extern "C" int bl_cast_bf16_f32(const bl_bf16* src, float* dst, int64_t n, void* stream) {
+  if (!src || !dst) return BL_E_ARG;
+  if (n <= 0) return BL_E_SHAPE;
+  if (!bl_aligned16(src) || !bl_aligned16(dst)) return BL_E_ALIGN;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, (long)n);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

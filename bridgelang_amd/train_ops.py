@@ -232,3 +232,10 @@ def transpose_pack_into(a: torch.Tensor, out: torch.Tensor, rows_pad: int, kt_to
     assert out.numel() == cols * kt_total * 32
     return _op("bl_transpose_pack_into_bf16", (_bf16(a, "a").data_ptr(), _rows(a, "a"), rows, cols, _bf16(out, "out").data_ptr(),
                                                rows_pad, kt_total, kb_offset), (a, out), run, nbytes=2.0 * cols * (rows + rows_pad))
+
+
+def cast(src: torch.Tensor, dst: torch.Tensor, run: bool = True) -> Op:
+    """fp32 → bf16 (round to nearest even) or bf16 → fp32 of flat contiguous buffers (gradient wire format)."""
+    assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+    name = {(torch.float32, torch.bfloat16): "bl_cast_f32_bf16", (torch.bfloat16, torch.float32): "bl_cast_bf16_f32"}[(src.dtype, dst.dtype)]
+    return _op(name, (src.data_ptr(), dst.data_ptr(), src.numel()), (src, dst), run, nbytes=6.0 * src.numel())

@@ -33,6 +33,15 @@ class Bucket:
 ALIGN = 8                      # elements: 16 bytes of bf16 per rank slice
 
 
+def _cast(src: torch.Tensor, dst: torch.Tensor) -> None:
+    """dtype-converting copy: the bl_cast_* kernels on the GPU (current stream), torch on CPU tensors (gloo tests)."""
+    if src.is_cuda:
+        from .. import train_ops
+        train_ops.cast(src, dst)
+    else:
+        dst.copy_(src)
+
+
 def bucket_key(name: str) -> str:
     """Communication bucket of a GEMM-weight group, from its first HF member name."""
     p = name.split(".")
@@ -109,10 +118,12 @@ class ShardLayout:
 class ShardComm:
     """The three collectives of a sharded-optimizer step. `group=None` with world 1 makes every call a no-op."""
 
-    def __init__(self, layout: ShardLayout, group=None, reduce_dtype: torch.dtype = torch.float32):
+    def __init__(self, layout: ShardLayout, group=None, reduce_dtype: torch.dtype = torch.float32, force: bool = False):
+        """`force=True` issues the collectives even at world size 1 (a one-rank RCCL group: exercises the exact calls,
+        views and dtypes of the multi-GPU path on a single-GPU box)."""
         self.layout, self.group = layout, group
         self.reduce_dtype = reduce_dtype
-        self.active = layout.world > 1
+        self.active = layout.world > 1 or force
         if self.active and not dist.is_initialized():
             raise RuntimeError("world > 1 needs an initialised process group")
         self._native_rs = self.active and dist.get_backend(group) == "nccl"
@@ -127,10 +138,10 @@ class ShardComm:
         full = grad[b.offset:b.offset + b.numel]
         if self.reduce_dtype != grad.dtype:
             send = scratch[:b.numel]
-            send.copy_(full)
+            _cast(full, send)
             mine = send[lo - b.offset:hi - b.offset]
             self._rs(mine, send)
-            grad[lo:hi].copy_(mine)
+            _cast(mine, grad[lo:hi])
         else:
             self._rs(grad[lo:hi], full)
 

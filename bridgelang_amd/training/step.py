@@ -217,7 +217,8 @@ class TrainStep:
 
     def __init__(self, weights: VLAWeights, stage: str, batch: int, prompt_len: int, *, max_grad_norm: float = 1.0,
                  weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8, store: Optional[ParamStore] = None,
-                 world: int = 1, rank: int = 0, group=None, reduce_dtype: torch.dtype = torch.float32, lora=None):
+                 world: int = 1, rank: int = 0, group=None, reduce_dtype: torch.dtype = torch.float32, lora=None,
+                 force_comm: bool = False):
         """`lora`: a training.lora.LoraAdapters → stage "lora": the base model is frozen and only the adapters train."""
         if (lora is not None) != (stage == "lora"):
             raise ValueError("stage 'lora' and the `lora` adapters go together")
@@ -234,7 +235,7 @@ class TrainStep:
         self.store = store
         assert self.store.stage == stage
         st = self.store
-        self.comm = ShardComm(st.layout, group, reduce_dtype)
+        self.comm = ShardComm(st.layout, group, reduce_dtype, force=force_comm)
         self.world = st.layout.world
         dev = weights.embed.device
         self.device = dev

@@ -93,3 +93,45 @@ def w0(name, dims, dev):
         from bridgelang_amd.weights import allocate
         _W0.update({k: v.float().cpu() for k, v in allocate(dims, dev).fill_synthetic(seed=3).state_dict().items()})
     return _W0[name]
+
+
+_RCCL_WORKER = r'''
+import os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["BL_ROOT"]); sys.path.insert(0, os.path.join(os.environ["BL_ROOT"], "tests"))
+from test_train_step_gpu import make_batch
+from bridgelang_amd.training.step import TrainStep
+from bridgelang_amd.weights import allocate, tiny_dims
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)               # RCCL, one rank
+dims = tiny_dims()
+out = {}
+for mode in ("plain", "rccl-fp32", "rccl-bf16"):
+    w = allocate(dims, dev).fill_synthetic(seed=3)
+    kw = {} if mode == "plain" else dict(force_comm=True, reduce_dtype=torch.bfloat16 if mode.endswith("bf16") else torch.float32)
+    ts = TrainStep(w, "vla-full-train", 2, 20, max_grad_norm=1.0, weight_decay=0.1, **kw)
+    log = []
+    for step in range(2):
+        ids, mask, labels, pv = make_batch(dims, 2, 20, seed=50 + step)
+        ts.set_batch(ids, mask, pv, labels)
+        loss, norm = ts.step(1e-3)
+        log.append((loss.item(), norm.item()))
+    out[mode] = (log, ts.store.full_master(ts.comm).cpu())
+assert out["plain"][0] == out["rccl-fp32"][0] and torch.equal(out["plain"][1], out["rccl-fp32"][1]), (out["plain"][0], out["rccl-fp32"][0])
+l0, l1 = out["plain"][0], out["rccl-bf16"][0]
+assert all(abs(a[1] - b[1]) <= 2e-2 * a[1] for a, b in zip(l0, l1)), (l0, l1)       # gradients crossed the wire as bf16
+print("RCCL_OK", l0, l1, flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_step_over_rccl_single_rank(dev, tmp_path):
+    """The multi-GPU code path with its real backend: a one-rank RCCL group with the collectives forced on (in-place
+    reduce_scatter_tensor / all_gather_into_tensor on bucket views, side-stream overlap, bf16 wire format). fp32 reduction
+    must reproduce the collective-free step bit for bit; bf16 reduction within its rounding."""
+    script = tmp_path / "worker.py"
+    script.write_text(_RCCL_WORKER)
+    env = dict(os.environ, BL_ROOT=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout[-3000:]
