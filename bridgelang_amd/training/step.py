@@ -18,7 +18,7 @@ MI355X-first choices (DESIGN.md "Training step"):
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -88,12 +88,19 @@ class ParamStore:
     copy on every rank, fp32 masters and AdamW moments for this rank's 1/world slice of every bucket only."""
 
     def __init__(self, w: VLAWeights, stage: str, world: int = 1, rank: int = 0,
-                 extra: Optional[List[Tuple[str, torch.Tensor, bool, str]]] = None):
+                 extra: Optional[List[Tuple[str, torch.Tensor, bool, str]]] = None, only: Optional[Sequence[str]] = None):
         """`extra`: additional trainable bf16 tensors outside the model's own table — (name, flat live tensor, decayed,
-        bucket key), e.g. LoRA adapters."""
+        bucket key), e.g. LoRA adapters. `only`: restrict the stage's trainable set to these HF names (whole fused groups;
+        diagnostics / tests: optimizer state for a handful of tensors instead of the model)."""
         self.w, self.stage = w, stage
         specs = w._specs()
         names = set(trainable_names(w, stage))
+        if only is not None:
+            keep = set(only)
+            for g in w.groups:
+                if keep & set(g.members):
+                    keep |= set(g.members)
+            names &= keep
         self.names = names
         self.units: List[Unit] = []
         self.by_name: Dict[str, Unit] = {}
