@@ -41,7 +41,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--prompt-len", type=int, default=32)
-    ap.add_argument("--model", default="openvla-7b", choices=["openvla-7b", "openvla-tiny"])
+    ap.add_argument("--model", default="openvla-7b", choices=["openvla-7b", "openvla-tiny", "prism-13b"])
     ap.add_argument("--no-graph", action="store_true", help="replay the op plan eagerly instead of as one HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
@@ -172,7 +172,7 @@ def main() -> None:
 
     from bridgelang_amd import weights as W
     from bridgelang_amd.engine import OpenVLAEngine
-    dims = W.openvla_7b_dims() if args.model == "openvla-7b" else W.tiny_dims()
+    dims = {"openvla-7b": W.openvla_7b_dims, "prism-13b": W.prism_13b_dims, "openvla-tiny": W.tiny_dims}[args.model]()
     w = W.allocate(dims, dev).fill_synthetic(seed=0)
     ids, pv = make_inputs(args.batch, args.prompt_len, seed=rank, device=dev)
 
@@ -221,8 +221,10 @@ def main() -> None:
         pmc = ROOT / "profiles" / "pmc_r01" / "gemm_traffic.json"
         if pmc.exists() and args.model == "openvla-7b" and args.batch == 16 and args.prompt_len == 32:
             traffic = round(json.loads(pmc.read_text())["avg_hbm_bytes_per_call_llama_layer"])
+        # algorithmic work per sequence: the SURVEY figure for the BASELINE model, the plan's own GEMM + attention FLOPs otherwise
+        algo = ALGO_TFLOP_PER_SEQ if args.model == "openvla-7b" else sum(op.flops for op in eng.all_ops()) / args.batch / 1e12
         line = {
-            "metric": "action-seqs/sec (7-DoF, 224px) openvla-7b bf16", "value": round(value, 3), "unit": "action-seqs/s",
+            "metric": f"action-seqs/sec (7-DoF, 224px) {dims.name} bf16", "value": round(value, 3), "unit": "action-seqs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -239,8 +241,8 @@ def main() -> None:
                          "kernel": "gemm256_kernel + gemm128_kernel tail (per bl_gemm_bf16 call)", "launches_per_step": gemm["launches"],
                          "avg_launch_us": round(gemm["ms"] * 1e3 / gemm["launches"], 2),
                          "algorithmic_gflop_per_launch": round(gemm["flops"] / gemm["launches"] / 1e9, 3)},
-            "end_to_end": {"algorithmic_tflop_per_seq": ALGO_TFLOP_PER_SEQ,
-                           "mfma_util_whole_step": round(value / world * ALGO_TFLOP_PER_SEQ / BF16_MFMA_PEAK_TFLOPS, 4),
+            "end_to_end": {"algorithmic_tflop_per_seq": round(algo, 3),
+                           "mfma_util_whole_step": round(value / world * algo / BF16_MFMA_PEAK_TFLOPS, 4),
                            "kernel_ms_per_step_eager_events": round(kern_ms, 3),
                            "per_kernel_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
                            "decode_weight_stream_GBs": (round(skinny["bytes"] / (skinny["ms"] * 1e-3) / 1e9, 1) if skinny else None),

@@ -87,6 +87,15 @@ def openvla_7b_dims() -> VLADims:
         llm_dim=4096, llm_layers=32, llm_heads=32, llm_inter=11008)
 
 
+def prism_13b_dims() -> VLADims:
+    """BASELINE configs[4] composition: `dinosiglip-vit-so-224px` + `llama2-13b-pure` + fused-gelu-mlp (not a registered
+    reference model id — SURVEY §8d cfg 5 — but every part is in the registries): hidden 5120, 40 layers / heads, 13824."""
+    return VLADims(
+        dino=TowerDims("vision_backbone.featurizer", 1024, 24, 16, 4096, 5, True, 0),
+        siglip=TowerDims("vision_backbone.fused_featurizer", 1152, 27, 16, 4304, 0, False, 3),
+        llm_dim=5120, llm_layers=40, llm_heads=40, llm_inter=13824, name="prism-dinosiglip-224px+13b")
+
+
 def tiny_dims(llm_layers: int = 2, depth: int = 3) -> VLADims:
     """Reduced widths with the same structure (head_dim 64/72/128, a ragged SigLIP MLP width) for oracle-speed tests."""
     return VLADims(
