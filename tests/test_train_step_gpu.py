@@ -138,3 +138,35 @@ def test_graph_replay_equals_eager_over_steps(dev, stage):
     print(out[False][0], out[True][0])
     assert out[False][0] == out[True][0]
     assert torch.equal(out[False][1], out[True][1])
+
+
+def test_edge_cases_max_length_and_unsupervised_sample(dev):
+    """(i) the longest plannable sequence (S = 320 = 256 patches + 64 text tokens) still matches autograd; (ii) a sample
+    with no supervised token contributes nothing (HF ignore_index semantics); (iii) over-long plans are rejected."""
+    from bridgelang_amd.training.step import TrainStep, trainable_names
+    from bridgelang_amd.weights import allocate, tiny_dims
+    dims = tiny_dims()
+    w = allocate(dims, dev).fill_synthetic(seed=8)
+    sd = {k: v.float().cpu() for k, v in w.state_dict().items()}
+    B, L = 2, 64
+    ids, mask, labels, pv = make_batch(dims, B, L, seed=3, ragged=False)
+    labels[1] = -100                                             # second sample: nothing supervised
+    ts = TrainStep(w, "vla-train", B, L)
+    assert ts.S == 320
+    ts.set_batch(ids, mask, pv, labels)
+    loss = ts.forward().item()
+    ts.backward()
+    names = trainable_names(w, "vla-train")
+    for n in names:
+        sd[n].requires_grad_(True)
+    ref = oracle_loss(sd, dims, ids, mask, labels, pv)
+    ref.backward()
+    assert abs(loss - ref.item()) <= 2e-3 * abs(ref.item())
+    for n in ("language_model.model.layers.0.self_attn.q_proj.weight", "projector.fc1.weight", "language_model.lm_head.weight",
+              "language_model.model.embed_tokens.weight"):
+        assert cos(ts.store.named_grad(n).float().cpu(), sd[n].grad) > 0.99, n
+    # the unsupervised sample's rows of dlogits are exactly zero
+    dl = ts.dlogits.view(B, ts.S, -1)
+    assert dl[1].abs().max().item() == 0.0 and dl[0].abs().max().item() > 0
+    with pytest.raises(ValueError):
+        TrainStep(w, "vla-train", B, 65, store=ts.store)
