@@ -10,7 +10,6 @@ only, modeling_prismatic.py:326,460-463); per-sample results equal independent b
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
 from typing import List, Optional
 
 import torch

@@ -9,7 +9,6 @@ from dataclasses import asdict, dataclass
 from pathlib import Path
 from typing import Any, Dict, Iterable, Optional
 
-import torch
 import torch.distributed as dist
 
 from .lora import LoraAdapters

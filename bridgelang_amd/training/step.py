@@ -25,7 +25,7 @@ import torch
 from .. import ops, train_ops as T
 from ..engine import rope_tables
 from ..ops import EPI_BIAS, EPI_F32, EPI_F32_BF16R, EPI_NONE, EPI_RES, Op
-from ..weights import PackedGroup, Placement, VLAWeights, _block_view, _unpack
+from ..weights import PackedGroup, VLAWeights, _block_view, _unpack
 from .sharding import ShardComm, ShardLayout, bucket_key, comm_order
 
 IGNORE_INDEX = -100

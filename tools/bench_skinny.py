@@ -1,5 +1,5 @@
 """Micro-benchmark of the weight-streaming (M<=16) GEMM on the Llama-2-7B decode shapes; prints achieved HBM GB/s."""
-import sys, time, torch
+import sys, torch
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from bridgelang_amd import ops
