@@ -98,6 +98,7 @@ SIGNATURES = {
     "bl_gemm_tn_small_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _i32, _f32, _vp, _i64, _vp]),
     "bl_scale_bf16": (C.c_int, [_vp, _f32, _vp, _i64, _vp]),
     "bl_lora_block_mask_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "bl_axpy_f32": (C.c_int, [_vp, _vp, _f32, _i64, _vp]),
     "bl_cast_f32_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
     "bl_cast_bf16_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "bl_memset_zero": (C.c_int, [_vp, _i64, _vp]),

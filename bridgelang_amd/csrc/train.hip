@@ -354,6 +354,16 @@ __global__ void lora_block_mask_kernel(float* g, int n_rows, int R, int rp, int 
   }
 }
 
+// ---- y += a·x on flat fp32 buffers: gradient accumulation over micro-batches (finetune.py:256-262, 307-310) ----
+__global__ void axpy_f32_kernel(float* y, const float* x, float a, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4_t xv = __builtin_nontemporal_load((const f32x4_t*)x + i);
+    ((f32x4_t*)y)[i] += xv * a;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += a * x[i];
+}
+
 // ---- wire format of the gradient reduce-scatter (fsdp.py:139-147 reduce_dtype = bf16): fp32 ↔ bf16 casts ----
 __global__ void cast_f32_bf16_kernel(const float* src, uint16_t* dst, long n) {
   const long n8 = n >> 3;
@@ -764,6 +774,15 @@ extern "C" int bl_lora_block_mask_f32(float* g, int32_t n_rows, int32_t R, int32
   if (n_rows <= 0 || R <= 0 || rp <= 0 || members <= 0 || R != rp * members || (n_rows % members)) return BL_E_SHAPE;
   hipLaunchKernelGGL(lora_block_mask_kernel, dim3(grid_for((long)n_rows * R, 256)), dim3(256), 0, (hipStream_t)stream, g,
                      n_rows, R, rp, members, interleave);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream) {
+  if (!y || !x) return BL_E_ARG;
+  if (n <= 0) return BL_E_SHAPE;
+  if (!bl_aligned16(y) || !bl_aligned16(x)) return BL_E_ALIGN;
+  hipLaunchKernelGGL(axpy_f32_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, y, x, a, (long)n);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

@@ -239,3 +239,9 @@ def cast(src: torch.Tensor, dst: torch.Tensor, run: bool = True) -> Op:
     assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
     name = {(torch.float32, torch.bfloat16): "bl_cast_f32_bf16", (torch.bfloat16, torch.float32): "bl_cast_bf16_f32"}[(src.dtype, dst.dtype)]
     return _op(name, (src.data_ptr(), dst.data_ptr(), src.numel()), (src, dst), run, nbytes=6.0 * src.numel())
+
+
+def axpy(y: torch.Tensor, x: torch.Tensor, a: float, run: bool = True) -> Op:
+    """y += a·x (flat fp32): gradient accumulation."""
+    assert y.is_contiguous() and x.is_contiguous() and y.numel() == x.numel()
+    return _op("bl_axpy_f32", (_f32(y, "y").data_ptr(), _f32(x, "x").data_ptr(), float(a), y.numel()), (y, x), run, nbytes=12.0 * y.numel())

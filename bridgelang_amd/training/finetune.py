@@ -44,8 +44,6 @@ def finetune(vlm, dataloader: Iterable[Dict[str, Any]], action_tokenizer, cfg: F
         raise NotImplementedError("4-bit base weights (bitsandbytes) are outside the MI355X path: 288 GB HBM holds bf16")
     if cfg.lora_dropout != 0.0:
         raise NotImplementedError("lora_dropout != 0 (reference default 0.0)")
-    if cfg.grad_accumulation_steps != 1:
-        raise NotImplementedError("gradient accumulation: raise batch_size instead (activations stay resident in 288 GB)")
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
     w = vlm.weights
     lora = LoraAdapters(w, r=cfg.lora_rank) if cfg.use_lora else None
@@ -69,17 +67,27 @@ def finetune(vlm, dataloader: Iterable[Dict[str, Any]], action_tokenizer, cfg: F
         logits = engine.logits.view(engine.B, engine.S, -1)[:, :num_patches + ids.shape[1]]
         m = vla_action_metrics(logits, batch["labels"], action_tokenizer, num_patches=num_patches)
         recent["loss"].append(float(loss)); recent["acc"].append(m["action_accuracy"]); recent["l1"].append(m["l1_loss"])
-        engine.clip_grad_norm()                       # max_norm = inf: only feeds the (unit) coefficient AdamW reads
-        engine.optimizer_step(cfg.learning_rate, graph=True)
-        step = batch_idx // cfg.grad_accumulation_steps
+        accum = cfg.grad_accumulation_steps
+        if accum > 1:                                  # normalized_loss = loss / accum (finetune.py:256-262)
+            if world > 1:
+                raise NotImplementedError("gradient accumulation with the sharded optimizer")
+            engine.accumulate(1.0 / accum)
+        if (batch_idx + 1) % accum == 0:               # finetune.py:307-310
+            if accum > 1:
+                engine.use_accumulated()
+            engine.clip_grad_norm()                    # max_norm = inf: only feeds the (unit) coefficient AdamW reads
+            engine.optimizer_step(cfg.learning_rate, graph=True)
+        step = batch_idx // accum                      # gradient step index (finetune.py:288)
+        window_done = (batch_idx + 1) % accum == 0
+        done_steps = (batch_idx + 1) // accum
         sm = {k: sum(v) / len(v) for k, v in recent.items()}
-        out.update(steps=step + 1, train_loss=sm["loss"], action_accuracy=sm["acc"], l1_loss=sm["l1"])
-        if log is not None and step % cfg.log_every == 0:
+        out.update(steps=done_steps, train_loss=sm["loss"], action_accuracy=sm["acc"], l1_loss=sm["l1"])
+        if log is not None and window_done and step % cfg.log_every == 0:
             log.write(json.dumps({"step": step, "train_loss": sm["loss"], "action_accuracy": sm["acc"], "l1_loss": sm["l1"]}) + "\n")
             log.flush()
-        if (step > 0 and step % cfg.save_steps == 0) or step + 1 == cfg.max_steps:
+        if window_done and ((step > 0 and step % cfg.save_steps == 0) or done_steps == cfg.max_steps):
             out.update(save_checkpoint(vlm, lora, engine, cfg, step, rank))
-        if step + 1 >= cfg.max_steps:
+        if done_steps >= cfg.max_steps:
             break
     if log is not None:
         log.close()

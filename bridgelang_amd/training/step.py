@@ -753,6 +753,19 @@ class TrainStep:
                 reduce(lay.buckets[i])
         main.wait_stream(self._comm_stream)
 
+    def accumulate(self, scale: float = 1.0) -> None:
+        """Gradient accumulation: add scale × (this micro-batch's gradients) to the accumulator (allocated on first use).
+        `use_accumulated()` then makes the accumulated sum the gradient the optimizer step sees."""
+        st = self.store
+        if getattr(st, "grad_acc", None) is None:
+            st.grad_acc = torch.zeros_like(st.grad)
+        T.axpy(st.grad_acc, st.grad, scale)
+
+    def use_accumulated(self) -> None:
+        st = self.store
+        st.grad.copy_(st.grad_acc)          # D2D copy (plumbing); the accumulator is cleared for the next window
+        T.fill_zero(st.grad_acc)
+
     def clip_grad_norm(self) -> torch.Tensor:
         """Global L2 norm over every trainable gradient + clip coefficient min(1, max_norm / (norm + 1e-6)), kept on
         the device (fsdp.py:238-240 → FSDP.clip_grad_norm_). Each rank sums its own slices; the partial sums are

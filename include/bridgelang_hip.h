@@ -247,6 +247,9 @@ int bl_gemm_tn_small_bf16(const bl_bf16* P, int64_t ldp, const bl_bf16* Q, int64
  * members), or n % members when the members' rows are interleaved). */
 int bl_scale_bf16(const bl_bf16* x, float s, bl_bf16* out, int64_t n, void* stream);
 int bl_lora_block_mask_f32(float* g, int32_t n_rows, int32_t R, int32_t rp, int32_t members, int32_t interleave, void* stream);
+/* y += a * x on flat fp32 buffers: gradient accumulation over micro-batches with the loss normalised by the number of
+ * accumulation steps (vla-scripts/finetune.py:256-262, 307-310). */
+int bl_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream);
 /* fp32 <-> bf16 casts of flat buffers: the bf16 wire format of the gradient reduce-scatter (fsdp.py:139-147,
  * `reduce_in_full_precision=False`); round-to-nearest-even. 16-byte aligned pointers. */
 int bl_cast_f32_bf16(const float* src, bl_bf16* dst, int64_t n, void* stream);

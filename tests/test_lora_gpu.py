@@ -155,3 +155,36 @@ def test_lora_three_step_loss_curve_vs_oracle(dev):
     print("lora loss curve", [round(x, 4) for x in got], "oracle", [round(x, 4) for x in want])
     assert all(abs(a - b) <= 5e-3 * abs(b) for a, b in zip(got, want))
     assert got[2] < got[0] - 0.02
+
+
+def test_gradient_accumulation_equals_one_big_batch(dev):
+    """Two micro-batches of 2 accumulated with loss / 2 (finetune.py:256-262) give the gradients of one batch of 4 (every
+    sample carries 8 supervised tokens, so the mean of the micro-batch means is the big-batch mean)."""
+    from bridgelang_amd.training.lora import LoraAdapters
+    from bridgelang_amd.training.step import TrainStep
+    from bridgelang_amd.weights import allocate, tiny_dims
+    dims = tiny_dims()
+    w = allocate(dims, dev).fill_synthetic(seed=3)
+    ids, mask, labels, pv = make_batch(dims, 4, 20, seed=9, ragged=False)
+    grads = {}
+    for mode in ("big", "accum"):
+        lora = LoraAdapters(w, r=32, seed=2)
+        lora.load_state_dict(random_adapters(lora, seed=4))
+        Bm = 4 if mode == "big" else 2
+        ts = TrainStep(w, "lora", Bm, 20, lora=lora, max_grad_norm=float("inf"), weight_decay=0.01)
+        if mode == "big":
+            ts.set_batch(ids, mask, pv, labels)
+            ts.forward(); ts.backward()
+        else:
+            for h in range(2):
+                sl = slice(2 * h, 2 * h + 2)
+                ts.set_batch(ids[sl], mask[sl], pv[sl], labels[sl])
+                ts.forward(); ts.backward()
+                ts.accumulate(0.5)
+            ts.use_accumulated()
+            assert ts.store.grad_acc.abs().max().item() == 0.0
+        grads[mode] = ts.store.grad.clone()
+    c = cos(grads["big"].cpu(), grads["accum"].cpu())
+    rel = ((grads["big"] - grads["accum"]).norm() / grads["big"].norm()).item()
+    print(f"accumulated vs big batch: cosine {c:.6f}, rel diff {rel:.4f}")
+    assert c > 0.999 and rel < 0.03
