@@ -182,6 +182,133 @@ __global__ __launch_bounds__(256) void gemm128_splitk_reduce_kernel(GemmArgs p) 
 }
 
 // ======================================================================================================================
+// "mid" kernel: ALL M ≤ 64·MB rows × (16·NB) columns per workgroup (batch-1 prefill S = 288, one image's ViT tokens, the
+// projector at one image): every weight byte leaves HBM exactly once per GEMM — these shapes are bound by the weight
+// stream, not by MFMA — while the activation K-slabs (M × 128 B per K-step) are re-read from L2 by every workgroup.
+// 4 waves, wave w owns rows [16·MB·w, 16·MB·(w+1)) × all NB column blocks; 3-stage LDS ring (≤ 144 KiB), two K-tiles of
+// LDS-DMA in flight behind a counted vmcnt. NB = 4 (64-column slabs) for wide layers; NB = 1 (16-column slabs) when 64
+// would leave most CUs without a workgroup (N = 4096 → 256 workgroups instead of 64). The K order of every output is the
+// tile kernels' (K-tile by K-tile, two 32-steps each), so results are bit-identical to theirs — a sequence's result does
+// not depend on the batch size it was run in. grid.y may slice K when the caller provides a workspace (opt-in).
+// ======================================================================================================================
+template <int EPI, int MB, int NB>
+__global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 64 * MB, BN = 16 * NB, NWAVE = 4, NST = 3;
+  constexpr int A_BYTES = BM * ROW_BYTES, BUF_BYTES = A_BYTES + NB * 2048;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // NST × BUF_BYTES
+  const int n0 = blockIdx.x * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kt32 = p.K >> 5;
+
+  const unsigned a_bytes = (unsigned)min((long)p.M * p.lda * 2, 0xffffffffL);
+  const unsigned w_bytes = (unsigned)min((long)p.N * p.K * 2, 0xffffffffL);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
+
+  // activation pieces: 8·MB × (8 rows × 128 B); wave takes pieces j*4 + wave. lane → (row = lane>>3, chunk = lane&7)
+  const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
+  unsigned voffA[2 * MB];
+#pragma unroll
+  for (int j = 0; j < 2 * MB; ++j) voffA[j] = (unsigned)(((long)((j * NWAVE + wave) * 8 + prow) * p.lda) * 2 + pchunk * 16);
+  // weight blocks (1 KiB each): NB n-tiles × 2 k-steps. NB = 4: wave w stages n-tile w (two pieces); NB = 1: waves 0 / 1
+  // stage k-step 0 / 1 of the single n-tile, waves 2 / 3 none (their counted waits are one piece shorter)
+  constexpr int WP = NB == 4 ? 2 : 1;
+  const bool has_w = NB == 4 || wave < 2;
+  unsigned voffW[WP];
+  int ldsW[WP];
+#pragma unroll
+  for (int q = 0; q < WP; ++q) {
+    const int nt = NB == 4 ? wave : 0, ks = NB == 4 ? q : (wave & 1);
+    voffW[q] = (unsigned)(((long)(n0 / 16 + nt) * kt32 + ks) * 1024 + lane * 16);
+    ldsW[q] = A_BYTES + (nt * 2 + ks) * 1024;
+  }
+
+#define BL_STAGE(BUF, KT)                                                                                   \
+  do {                                                                                                      \
+    char* base__ = smem + (BUF) * BUF_BYTES;                                                                \
+    _Pragma("unroll") for (int j = 0; j < 2 * MB; ++j) BL_GLDS(rsA, base__ + (j * NWAVE + wave) * 1024, voffA[j], (KT) * 128); \
+    if (has_w) {                                                                                            \
+      _Pragma("unroll") for (int q = 0; q < WP; ++q) BL_GLDS(rsW, base__ + ldsW[q], voffW[q], (KT) * 2048); \
+    }                                                                                                       \
+  } while (0)
+#define BL_WAIT_TILES(T)                                                                                    \
+  do {                                                                                                      \
+    if (has_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((T) * (2 * MB + WP)) : "memory");                   \
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((T) * (2 * MB)) : "memory");                              \
+  } while (0)
+
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int c0 = lg ^ (lane & 7);
+  const int offA = (wave * 16 * MB + l15) * ROW_BYTES;
+  const int offW = A_BYTES + lane * 16;                 // block i*2 + ks
+
+  f32x4_t acc[NB][MB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < MB; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nk_all = p.K / BK;
+  int kt0 = 0, nk = nk_all;
+  if (p.splitk > 1) {
+    kt0 = (int)(((long)blockIdx.y * nk_all) / p.splitk);
+    nk = (int)(((long)(blockIdx.y + 1) * nk_all) / p.splitk);
+  }
+  BL_STAGE(0, kt0);
+  if (kt0 + 1 < nk) BL_STAGE(1, kt0 + 1);
+  for (int kt = kt0; kt < nk; ++kt) {
+    const int it = kt - kt0;
+    if (kt + 2 < nk) {                 // the ring slot read in the previous iteration (all waves are past its barrier)
+      BL_STAGE((it + 2) % NST, kt + 2);
+      BL_WAIT_TILES(2);
+    } else if (kt + 1 < nk) {
+      BL_WAIT_TILES(1);
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();      // every wave's pieces of K-tile kt have landed
+    const char* base = smem + (it % NST) * BUF_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int cb = (c0 ^ (ks * 4)) << 4;
+      bf16x8_t wf[NB], af[MB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) wf[i] = *(const bf16x8_t*)(base + offW + (i * 2 + ks) * 1024);
+#pragma unroll
+      for (int j = 0; j < MB; ++j) af[j] = *(const bf16x8_t*)(base + offA + j * 16 * ROW_BYTES + cb);
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < MB; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // all reads of this slot done before it is re-issued next iteration
+  }
+#undef BL_STAGE
+#undef BL_WAIT_TILES
+  if (p.splitk > 1) {
+    float* slab = p.slab + (long)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int j = 0; j < MB; ++j) {
+        const int m = wave * 16 * MB + j * 16 + l15, n = n0 + i * 16 + lg * 4;
+        if (m < p.M && n < p.N) *(f32x4_t*)(slab + (long)m * p.N + n) = acc[i][j];
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < MB; ++j)
+      epilogue_store4<EPI>(p, wave * 16 * MB + j * 16 + l15, n0 + i * 16 + lg * 4, acc[i][j]);
+#endif
+}
+
+// ======================================================================================================================
 // 256 × 256 tile, half-tile LDS-DMA ring, 4 phases per K-tile
 // ======================================================================================================================
 template <int EPI>
@@ -569,6 +696,14 @@ __global__ __launch_bounds__(512) void gemm_splitk_reduce_kernel(GemmArgs p) {
   epilogue_store4<EPI>(p, tm * 256 + wm * 128 + j * 16 + l15, tn * 256 + wn * 64 + i * 16 + lg * 4, sum);
 }
 
+template <int MB, int NB>
+constexpr int mid_lds_bytes() { return 3 * (64 * MB * ROW_BYTES + NB * 2048); }
+template <int EPI, int MB, int NB>
+bool mid_attr() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mid_kernel<EPI, MB, NB>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, mid_lds_bytes<MB, NB>()) == hipSuccess;
+}
+
 template <int EPI>
 int set_lds_attr() {
   static bool done = false;   // idempotent; a benign race only repeats the same calls
@@ -578,7 +713,9 @@ int set_lds_attr() {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128_kernel<EPI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * ROW_BYTES) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * ROW_BYTES) != hipSuccess ||
+        !mid_attr<EPI, 2, 4>() || !mid_attr<EPI, 4, 4>() || !mid_attr<EPI, 5, 4>() || !mid_attr<EPI, 2, 1>() ||
+        !mid_attr<EPI, 4, 1>() || !mid_attr<EPI, 5, 1>())
       return BL_E_LAUNCH;
     done = true;
   }
@@ -595,6 +732,35 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   const int bm = (p.M + 255) / 256, bn = (p.N + 255) / 256, big_tiles = bm * bn;
   bool big = big_tiles >= CUS && p.K >= 512;
   if (force) big = force[0] == '2';
+  static const bool no_mid = getenv("BL_GEMM_NO_MID") != nullptr;      // A/B aid
+  if (p.M <= 320 && p.M > 32 && p.K >= 512 && !force && !no_mid) {
+    // every weight byte once: one workgroup per column slab, all rows; 64-column slabs when that already gives ≥ 160
+    // workgroups, else 16-column slabs. grid.y slices K only with a workspace (opt-in).
+    const bool wide = (p.N + 63) / 64 >= 160;
+    const int slabs = wide ? (p.N + 63) / 64 : (p.N + 15) / 16, nkm = p.K / BK;
+    int S = 1;
+    if (p.slab && !getenv("BL_GEMM_NO_SPLITK") && slabs < CUS) {
+      S = min(8, (CUS + CUS / 2 + slabs - 1) / slabs);
+      while (S > 1 && (nkm / S < 8 || p.slab_bytes < (long)S * p.M * p.N * 4)) --S;
+    }
+    p.splitk = S;
+    const dim3 grid(slabs, S), block(256);
+#define BL_MID(MBV)                                                                                            \
+  do {                                                                                                         \
+    if (wide) hipLaunchKernelGGL((gemm_mid_kernel<EPI, MBV, 4>), grid, block, (mid_lds_bytes<MBV, 4>()), s, p);  \
+    else hipLaunchKernelGGL((gemm_mid_kernel<EPI, MBV, 1>), grid, block, (mid_lds_bytes<MBV, 1>()), s, p);       \
+  } while (0)
+    if (p.M <= 128) BL_MID(2);
+    else if (p.M <= 256) BL_MID(4);
+    else BL_MID(5);
+#undef BL_MID
+    if (S > 1) {
+      const long work = (long)p.M * (p.N / 4);
+      hipLaunchKernelGGL((gemm128_splitk_reduce_kernel<EPI>), dim3((int)min((work + 255) / 256, 2048L)), dim3(256), 0, s, p);
+    }
+    BL_CHECK_LAUNCH();
+    return BL_OK;
+  }
   if (!big) {
     p.tiles_m = (p.M + 127) / 128;
     p.tiles_n = (p.N + 127) / 128;

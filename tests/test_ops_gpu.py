@@ -363,3 +363,35 @@ def test_preprocess_uint8_frames_bit_exact(dev):
     ref = torch.stack([ip.apply_transform(Image.fromarray(f)) for f in frames]).to(torch.bfloat16)
     got = ip.preprocess_frames_gpu(torch.from_numpy(frames).to(dev))
     assert got.shape == (3, 6, 224, 224) and torch.equal(got.cpu(), ref)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(288, 12288, 4096, "none"), (288, 4096, 1024, "res"), (261, 1024, 4096, "res"), (256, 4352, 1152, "gelu"),
+                                       (100, 192, 512, "gelu"), (33, 64, 1536, "none"), (320, 3072, 1536, "swiglu"), (288, 256, 1088, "res")])
+def test_gemm_mid_rows(dev, M, N, K, epi):
+    """16 < M <= 320 (batch-1 prefill, one image's tokens): the weight-streaming mid kernel vs the oracle, bit-identical
+    to the tile kernels (same K order) so a row's result does not depend on how many rows ran with it; K-sliced with a
+    workspace stays within rounding."""
+    from bridgelang_amd import ops
+    Mbig = 700
+    a, w, b, r = rand_bf16((Mbig, K), 1), rand_bf16((N, K), 2, 0.05), rand_bf16((N,), 3, 0.1), rand_bf16((Mbig, N), 4)
+    A, Bv, Rr = dv(a, dev), dv(b, dev), dv(r, dev)
+    if epi == "swiglu":
+        I = N // 2
+        W = pk(torch.stack([w[:I], w[I:]], 1).reshape(N, K), dev)
+        code, kw, ncols = ops.EPI_SWIGLU, {}, I
+        g, u = R.linear(P, a[:M], w[:I]), R.linear(P, a[:M], w[I:])
+        ref = P.rb(P.rb(torch.nn.functional.silu(g)) * u)
+    else:
+        W = pk(w, dev)
+        code = {"res": ops.EPI_RES, "gelu": ops.EPI_BIAS_GELU, "none": ops.EPI_NONE}[epi]
+        kw, ncols = {"res": dict(res=Rr), "gelu": dict(bias=Bv), "none": {}}[epi], N
+        lin = R.linear(P, a[:M], w, b if epi == "gelu" else None)
+        ref = {"res": lambda: P.rb(r[:M] + lin), "gelu": lambda: R.gelu(P, lin), "none": lambda: lin}[epi]()
+    out, big, out_ws = (torch.zeros(Mbig, ncols, dtype=torch.bfloat16, device=dev) for _ in range(3))
+    kws = {k: (v[:M] if k == "res" else v) for k, v in kw.items()}
+    ops.gemm(A[:M], W, out[:M], code, **kws)                                   # mid kernel
+    ops.gemm(A, W, big, code, **kw)                                            # tile kernels on 700 rows
+    close_bf16(out[:M], ref, f"mid {epi}")
+    assert torch.equal(out[:M], big[:M]), "a row's result must not depend on the number of rows in the call"
+    ops.gemm(A[:M], W, out_ws[:M], code, workspace=torch.empty(64 << 20, dtype=torch.uint8, device=dev), **kws)
+    close_bf16(out_ws[:M], ref, f"mid {epi} (K-sliced)")
