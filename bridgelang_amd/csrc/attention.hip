@@ -247,10 +247,15 @@ __global__ __launch_bounds__(512) void attn_seq_kernel(AttnArgs p, int s_pad) {
   }
   __syncthreads();
 
+  // query tiles, heaviest (causal) first: with few (batch, head) pairs (batch-1 serving: 32 workgroups on 256 CUs) gridDim.y
+  // workgroups share a head — workgroup y takes tiles y, y + gridDim.y, … and stages K / V itself (L2-resident)
   const int nqt = (p.Sq + 15) >> 4;
-  for (int r = 0; r * 8 < nqt; ++r) {
-    const int idx = r * 8 + ((r & 1) ? 7 - wave : wave);
-    if (idx >= nqt) continue;                       // wave-uniform
+  const int nsp = gridDim.y, sp = blockIdx.y;
+  const int nloc = (nqt - sp + nsp - 1) / nsp;
+  for (int r = 0; r * 8 < nloc; ++r) {
+    const int local = r * 8 + ((r & 1) ? 7 - wave : wave);
+    if (local >= nloc) continue;                    // wave-uniform
+    const int idx = local * nsp + sp;
     const int qt = nqt - 1 - idx, q0 = qt * 16, qrow = q0 + l15;
     int kv_hi = p.Skv;
     if (CAUSAL) kv_hi = min(p.Skv, q0 + 16 + off);
@@ -512,7 +517,9 @@ int launch_seq(const AttnArgs& a, const bl_attn_desc* d, hipStream_t s) {
       return BL_E_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_seq_kernel<HD, CAUSAL>), dim3(d->B * d->H), dim3(512), lds, s, a, s_pad);
+  const int heads = d->B * d->H;
+  const int nsp = heads >= 128 ? 1 : (heads >= 64 ? 2 : 4);
+  hipLaunchKernelGGL((attn_seq_kernel<HD, CAUSAL>), dim3(heads, nsp), dim3(512), lds, s, a, s_pad);
   return BL_OK;
 }
 
