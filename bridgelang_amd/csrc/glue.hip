@@ -263,7 +263,7 @@ inline int grid_for(long total, int block) {
 }  // namespace bl_glue_impl
 using namespace bl_glue_impl;
 
-extern "C" int bl_abi_version(void) { return 1; }
+extern "C" int bl_abi_version(void) { return 2; }   // 2: leading dimensions on rope / gelu, alpha on the TN GEMM
 extern "C" const char* bl_build_arch(void) { return "gfx950"; }
 
 extern "C" int bl_fill_synth_bf16_2d(bl_bf16* dst, int64_t rows, int64_t cols, int64_t ld, uint32_t seed, float mean,
