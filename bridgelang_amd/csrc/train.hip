@@ -263,7 +263,7 @@ __global__ void gelu_bwd_kernel(const uint16_t* x, long ldx, const uint16_t* dy,
     unpack8(*(const u32x4_t*)(dy + r * lddy + c), d);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      d[i] *= 0.5f * (1.0f + erff(v[i] * 0.70710678118654752440f)) + v[i] * 0.39894228040143267794f * expf(-0.5f * v[i] * v[i]);
+      d[i] *= 0.5f * (1.0f + erf_as(v[i] * 0.70710678118654752440f)) + v[i] * 0.39894228040143267794f * __expf(-0.5f * v[i] * v[i]);
     *(u32x4_t*)(dx + r * lddx + c) = pack8(d);
   }
 }
@@ -660,7 +660,7 @@ static int norm_backward(const bl_bf16* x, int64_t ldx, const bl_bf16* w, const 
   if (!x || !w || !dy || !dx || !dw || !partial_ws || (LN && !db)) return BL_E_ARG;
   if (rows <= 0 || dim <= 0 || (dim % 8) || dim > 64 * 8 * 10) return BL_E_SHAPE;
   if ((ldx % 8) || (lddy % 8) || (lddx % 8) || (dres && (lddres % 8))) return BL_E_ALIGN;
-  // rows per block: as few as the partial workspace allows (>= 16: four rows per wave), so the grid covers the chip
+  // rows per block: as few as the partial workspace allows (>= 16: four rows per wave; fewer rows per block cost more in dw partial traffic than they gain in occupancy), so the grid covers the chip
   int rpb = 16;
   while ((int64_t)((rows + rpb - 1) / rpb) * dim * (LN ? 2 : 1) > partial_ws_floats) {
     rpb *= 2;
