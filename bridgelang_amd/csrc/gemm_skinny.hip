@@ -133,9 +133,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, int n_
 template <int KS, int GS, int EPI>
 int launch_ks(const GemmArgs& a, hipStream_t s) {
   const int n_tiles = a.N / 16;
-  const int per_cu = (KS <= 24) ? 2 : 1;          // x fragments cost 4·KS VGPRs per lane
-  // balanced tiles per workgroup: e.g. 768 tiles on 512 slots → 384 workgroups × 2 tiles (not 256 × 2 + 256 × 1)
-  const int tpw = (n_tiles + 256 * per_cu - 1) / (256 * per_cu);
+  // One 8-wave workgroup per CU: every variant needs > 128 VGPRs (x fragments 4·KS, two weight buffers, the fused-norm
+  // weights: 148–254), so two workgroups never co-reside; a grid of 384 (768 tiles ÷ 2) ran as 1.5 rounds of 256.
+  // Balanced tiles per workgroup on 256 slots: 768 tiles → 256 × 3; 1376 → 230 × 6 (not 256 × 5 + 96 stragglers).
+  const int tpw = (n_tiles + 255) / 256;
   const int grid = (n_tiles + tpw - 1) / tpw;
   if (a.norm_w) hipLaunchKernelGGL((gemm_skinny_kernel<KS, GS, EPI, true>), dim3(grid), dim3(NW * 64), 0, s, a, n_tiles);
   else hipLaunchKernelGGL((gemm_skinny_kernel<KS, GS, EPI, false>), dim3(grid), dim3(NW * 64), 0, s, a, n_tiles);
