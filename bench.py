@@ -250,7 +250,7 @@ def main() -> None:
                                                    "ms_per_step": round(elapsed_single / args.steps * 1e3, 3)},
                            "first_ids": ids_out[0].tolist()},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would wait at the barrier)
             line["cpu_baseline"] = cpu_baseline(dims, args.batch, args.prompt_len)
         print(json.dumps(line), flush=True)
     if distributed:
