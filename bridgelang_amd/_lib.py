@@ -68,6 +68,7 @@ SIGNATURES = {
     "bl_layernorm_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "bl_rmsnorm_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "bl_attention_bf16": (C.c_int, [C.POINTER(AttnDesc), _vp]),
+    "bl_attention_rope_bf16": (C.c_int, [C.POINTER(AttnDesc), _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "bl_attention_lse_bf16": (C.c_int, [C.POINTER(AttnDesc), _vp, _vp]),
     "bl_attention_backward_bf16": (C.c_int, [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bl_attention_decode_bf16": (C.c_int, [C.POINTER(AttnDesc), _vp]),

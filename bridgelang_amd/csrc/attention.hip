@@ -27,7 +27,31 @@ struct AttnArgs {
   float scale_log2e;
   float* lse;      // optional [B*H, lse_rs] base-2 log-sum-exp of the scaled scores (training forward); +inf for empty rows
   int lse_rs;
+  // fused RoPE + KV-cache write (whole-sequence kernel, head_dim 128): q / k are rotated while they are loaded, the rotated
+  // k and v rows are also written to the caches [B, H, cache_len, 128] at positions pos0 + key
+  const uint16_t* cos_tab; const uint16_t* sin_tab; uint16_t* k_cache; uint16_t* v_cache; int cache_len, pos0;
 };
+
+// HF apply_rotary_pos_emb on one 8-element chunk pair (x1 = dims c..c+7, x2 = dims 64+c..): the arithmetic (three bf16
+// roundings per element) of rope_kvcache_kernel in glue.hip, bit for bit.
+__device__ __forceinline__ void rope_pair(const u32x4_t x1, const u32x4_t x2, const u32x4_t cq, const u32x4_t sq, u32x4_t& o1,
+                                          u32x4_t& o2) {
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    float r1[2], r2[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float a = e ? bfhi(x1[w]) : bflo(x1[w]);
+      const float c2 = e ? bfhi(x2[w]) : bflo(x2[w]);
+      const float co = e ? bfhi(cq[w]) : bflo(cq[w]);
+      const float si = e ? bfhi(sq[w]) : bflo(sq[w]);
+      r1[e] = rbf(a * co) + rbf(-c2 * si);
+      r2[e] = rbf(c2 * co) + rbf(a * si);
+    }
+    o1[w] = pack2bf(r1[0], r1[1]);
+    o2[w] = pack2bf(r2[0], r2[1]);
+  }
+}
 
 constexpr int KV_CHUNK = 64;
 constexpr int VROW = KV_CHUNK * 2 + 16;   // bytes per V^T row (64 keys + 16 B pad → conflict-free ds_read_b64)
@@ -193,8 +217,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 // tiles with no further barriers: full score row in registers (≤ 20 key tiles × 4 fp32), exact two-pass softmax (no
 // online rescaling — the oracle's algorithm), P → bf16 → PV with transposing LDS reads. Query tiles are dealt to the 8
 // waves in snake order from the heaviest (causal) tile down, so wave loads differ by < 10 %.
-template <int HD, bool CAUSAL>
+template <int HD, bool CAUSAL, bool ROPE = false>
 __global__ __launch_bounds__(512) void attn_seq_kernel(AttnArgs p, int s_pad) {
+  static_assert(!ROPE || HD == 128, "fused RoPE is built for head_dim 128");
   constexpr int HDP = (HD + 31) / 32 * 32;
   constexpr int KS = HDP / 32;
   constexpr int KCH = HD / 8;                       // 16-byte chunks per row in HBM
@@ -220,7 +245,48 @@ __global__ __launch_bounds__(512) void attn_seq_kernel(AttnArgs p, int s_pad) {
   // ---- stage K and V once: chunk c of key row r lives at r*ROWB + ((c ^ (r & MASK)) << 4). One pass over all
   //      s_pad × CH LDS chunks (pad rows / pad chunks get zeros); loads are issued 6 deep per tensor before the
   //      LDS writes so a thread pays the global-load latency once per batch, not once per chunk. ----
-  {
+  if constexpr (ROPE) {
+    // one piece = the chunk pair (ch, ch + 8) of one key row: rotate k, copy v, fill LDS and (first workgroup of the head)
+    // the KV cache rows pos0 + key — what bl_rope_kvcache_bf16 did in a pass of its own over the fused qkv buffer
+    constexpr int UNR = 3;
+    const int npieces = s_pad * 8;
+    const long cache_base = ((long)b * p.H + h) * p.cache_len;
+    for (int base = tid; base < npieces; base += 512 * UNR) {
+      u32x4_t k1[UNR], k2[UNR], v1[UNR], v2[UNR], cq[UNR], sq[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int piece = base + u * 512, key = piece >> 3, ch = piece & 7;
+        k1[u] = k2[u] = v1[u] = v2[u] = cq[u] = sq[u] = (u32x4_t){0u, 0u, 0u, 0u};
+        if (piece < npieces && key < p.Skv) {
+          const uint16_t* kr = kbase + (long)key * p.k_rs + ch * 8;
+          const uint16_t* vr = vbase + (long)key * p.v_rs + ch * 8;
+          k1[u] = *(const u32x4_t*)kr; k2[u] = *(const u32x4_t*)(kr + 64);
+          v1[u] = *(const u32x4_t*)vr; v2[u] = *(const u32x4_t*)(vr + 64);
+          cq[u] = *(const u32x4_t*)(p.cos_tab + (long)(p.pos0 + key) * 64 + ch * 8);
+          sq[u] = *(const u32x4_t*)(p.sin_tab + (long)(p.pos0 + key) * 64 + ch * 8);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int piece = base + u * 512, key = piece >> 3, ch = piece & 7;
+        if (piece < npieces) {
+          u32x4_t o1, o2;
+          rope_pair(k1[u], k2[u], cq[u], sq[u], o1, o2);
+          *(u32x4_t*)(k_lds + key * ROWB + ((ch ^ (key & MASK)) << 4)) = o1;
+          *(u32x4_t*)(k_lds + key * ROWB + (((ch + 8) ^ (key & MASK)) << 4)) = o2;
+          const int pr1 = ((ch >> 1) ^ ((key >> VSH) & VPM)), pr2 = (((ch + 8) >> 1) ^ ((key >> VSH) & VPM));
+          *(u32x4_t*)(v_lds + key * ROWB + (((pr1 << 1) | (ch & 1)) << 4)) = v1[u];
+          *(u32x4_t*)(v_lds + key * ROWB + (((pr2 << 1) | (ch & 1)) << 4)) = v2[u];
+          if (blockIdx.y == 0 && key < p.Skv) {
+            uint16_t* kc = p.k_cache + (cache_base + p.pos0 + key) * 128 + ch * 8;
+            uint16_t* vc = p.v_cache + (cache_base + p.pos0 + key) * 128 + ch * 8;
+            *(u32x4_t*)kc = o1; *(u32x4_t*)(kc + 64) = o2;
+            *(u32x4_t*)vc = v1[u]; *(u32x4_t*)(vc + 64) = v2[u];
+          }
+        }
+      }
+    }
+  } else {
     constexpr int CH = ROWB / 16, UNR = 6;
     const int npieces = s_pad * CH;
     for (int base = tid; base < npieces; base += 512 * UNR) {
@@ -269,6 +335,19 @@ __global__ __launch_bounds__(512) void attn_seq_kernel(AttnArgs p, int s_pad) {
         u32x4_t t = {0u, 0u, 0u, 0u};
         if (qrow < p.Sq && ch < KCH) t = *(const u32x4_t*)(qp + ch * 8);
         qf[ks] = __builtin_bit_cast(bf16x8_t, t);
+      }
+      if constexpr (ROPE) {   // the lane holds chunks lg, lg+4 | lg+8, lg+12: both halves of two rotation pairs
+        const int pos = p.pos0 + min(qrow, p.Sq - 1);
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const int c = lg + 4 * pr;
+          const u32x4_t cq = *(const u32x4_t*)(p.cos_tab + (long)pos * 64 + c * 8);
+          const u32x4_t sq = *(const u32x4_t*)(p.sin_tab + (long)pos * 64 + c * 8);
+          u32x4_t o1, o2;
+          rope_pair(__builtin_bit_cast(u32x4_t, qf[pr]), __builtin_bit_cast(u32x4_t, qf[pr + 2]), cq, sq, o1, o2);
+          qf[pr] = __builtin_bit_cast(bf16x8_t, o1);
+          qf[pr + 2] = __builtin_bit_cast(bf16x8_t, o2);
+        }
       }
     }
     // ---- S^T = K · Q^T for every needed key tile ----
@@ -499,6 +578,7 @@ int fill_args(const bl_attn_desc* d, AttnArgs& a) {
   a.B = d->B; a.H = d->H; a.Sq = d->Sq; a.Skv = d->Skv;
   a.scale_log2e = d->scale * 1.44269504088896340736f;
   a.lse = nullptr; a.lse_rs = 0;
+  a.cos_tab = a.sin_tab = nullptr; a.k_cache = a.v_cache = nullptr; a.cache_len = a.pos0 = 0;
   return BL_OK;
 }
 
@@ -557,6 +637,30 @@ static int attention_launch(const bl_attn_desc* d, float* lse, void* stream) {
 }
 
 extern "C" int bl_attention_bf16(const bl_attn_desc* d, void* stream) { return attention_launch(d, nullptr, stream); }
+
+extern "C" int bl_attention_rope_bf16(const bl_attn_desc* d, const bl_bf16* cos_tab, const bl_bf16* sin_tab, int32_t pos0,
+                                      bl_bf16* k_cache, bl_bf16* v_cache, int32_t cache_len, void* stream) {
+  AttnArgs a;
+  const int rc = fill_args(d, a);
+  if (rc != BL_OK) return rc;
+  if (!cos_tab || !sin_tab || !k_cache || !v_cache) return BL_E_ARG;
+  if (d->head_dim != 128 || !d->causal || d->Skv != d->Sq || d->Sq > 320 || pos0 < 0 || pos0 + d->Skv > cache_len) return BL_E_SHAPE;
+  if (!bl_aligned16(cos_tab) || !bl_aligned16(sin_tab) || !bl_aligned16(k_cache) || !bl_aligned16(v_cache)) return BL_E_ALIGN;
+  a.cos_tab = cos_tab; a.sin_tab = sin_tab; a.k_cache = k_cache; a.v_cache = v_cache; a.cache_len = cache_len; a.pos0 = pos0;
+  const int s_pad = (d->Skv + 31) / 32 * 32, lds = 2 * s_pad * 256;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_seq_kernel<128, true, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return BL_E_LAUNCH;
+    attr_set = true;
+  }
+  const int heads = d->B * d->H;
+  const int nsp = heads >= 128 ? 1 : (heads >= 64 ? 2 : 4);
+  hipLaunchKernelGGL((attn_seq_kernel<128, true, true>), dim3(heads, nsp), dim3(512), lds, (hipStream_t)stream, a, s_pad);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
 
 extern "C" int bl_attention_lse_bf16(const bl_attn_desc* d, float* lse, void* stream) {
   if (!lse) return BL_E_ARG;

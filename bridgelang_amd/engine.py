@@ -148,9 +148,19 @@ class OpenVLAEngine:
         for l, lw in enumerate(w.layers):
             plan.append(ops.rmsnorm(x, lw.ln1, self.h, d.rms_eps, run=False))
             plan.append(self._g(self.h, lw.qkv_w, self.qkv, EPI_NONE, run=False))
+            last = last_rows_only and l == d.llm_layers - 1
+            if not last and hd == 128 and S <= 320:
+                # RoPE and the KV-cache write ride inside the attention kernel's q / k / v loads
+                plan.append(ops.attention_rope(self.qkv, self.k_cache[l], self.v_cache[l], self.ao, self.cos, self.sin, B=B,
+                                               S=S, H=H, head_dim=hd, pos0=0, key_mask=self.key_mask, run=False))
+                plan.append(self._g(self.ao, lw.o_w, x, EPI_RES, res=x, run=False))
+                plan.append(ops.rmsnorm(x, lw.ln2, self.h, d.rms_eps, run=False))
+                plan.append(self._g(self.h, lw.gu_w, self.act, EPI_SWIGLU, run=False))
+                plan.append(self._g(self.act, lw.down_w, x, EPI_RES, res=x, run=False))
+                continue
             plan.append(ops.rope_kvcache(self.qkv, self.cos, self.sin, self.k_cache[l], self.v_cache[l], B=B, S=S, H=H,
                                          head_dim=hd, pos0=0, run=False))
-            if last_rows_only and l == d.llm_layers - 1:
+            if last:
                 q_last = self.qkv.view(B, S, 3 * D)[:, S - 1]                  # roped in place; row stride S·3D
                 x_last = self.x[:, S - 1, :]
                 plan.append(ops.attention_decode(q_last, self.k_cache[l], self.v_cache[l], self.aod, B=B, H=H, Skv=S,

@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import (AttnDesc, GemmDesc, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_F32, EPI_F32_BF16R, EPI_NONE,
                    EPI_RES, EPI_SWIGLU)
 
-__all__ = ["Op", "gemm", "pack_weight", "unpack_weight", "cross_entropy", "layernorm", "rmsnorm", "attention", "attention_decode", "attention_decode_rope", "skinny_supported", "rope_kvcache", "embed_splice",
+__all__ = ["Op", "gemm", "pack_weight", "unpack_weight", "cross_entropy", "layernorm", "rmsnorm", "attention", "attention_rope", "attention_decode", "attention_decode_rope", "skinny_supported", "rope_kvcache", "embed_splice",
            "argmax", "im2col_patch14", "preprocess_u8", "write_prefix_tokens", "fill_synth", "run_all",
            "EPI_NONE", "EPI_BIAS", "EPI_BIAS_GELU", "EPI_BIAS_RES", "EPI_RES", "EPI_SWIGLU", "EPI_F32", "EPI_F32_BF16R"]
 
@@ -204,6 +204,29 @@ def attention(q, k, v, o, *, B: int, H: int, Sq: int, Skv: int, head_dim: int, q
     d = _attn_desc(q, k, v, o, B, H, Sq, Skv, head_dim, q_strides, k_strides, v_strides, o_strides, causal, scale,
                    key_mask)
     op = Op("bl_attention_bf16", lib.bl_attention_bf16, (C.byref(d),), (d, q, k, v, o, key_mask))
+    if run:
+        op.run()
+    return op
+
+
+def attention_rope(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, o: torch.Tensor, cos: torch.Tensor,
+                   sin: torch.Tensor, *, B: int, S: int, H: int, head_dim: int, pos0: int = 0, scale: Optional[float] = None,
+                   key_mask: Optional[torch.Tensor] = None, run: bool = True) -> Op:
+    """Prefill attention over fused, un-rotated qkv rows [B*S, 3*H*hd] with RoPE and the KV-cache write fused in
+    (bl_attention_rope_bf16): caches [B, H, cache_len, hd] receive rotated k and v at positions pos0.., o [B*S, H*hd]."""
+    lib = _lib.load()
+    D = H * head_dim
+    for t, n in ((qkv, "qkv"), (k_cache, "k_cache"), (v_cache, "v_cache"), (cos, "cos"), (sin, "sin")):
+        _bf16(t, n)
+        if not t.is_contiguous():
+            raise ValueError(f"attention_rope: {n} must be contiguous")
+    cache_len = k_cache.shape[2]
+    scale = head_dim ** -0.5 if scale is None else scale
+    st = (S * 3 * D, head_dim, 3 * D)
+    d = _attn_desc(qkv, qkv[:, D:], qkv[:, 2 * D:], o, B, H, S, S, head_dim, st, st, st, (S * D, head_dim, D), True, scale, key_mask)
+    op = Op("bl_attention_rope_bf16", lib.bl_attention_rope_bf16,
+            (C.byref(d), cos.data_ptr(), sin.data_ptr(), pos0, k_cache.data_ptr(), v_cache.data_ptr(), cache_len),
+            (d, qkv, k_cache, v_cache, o, cos, sin, key_mask))
     if run:
         op.run()
     return op

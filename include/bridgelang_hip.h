@@ -126,6 +126,13 @@ typedef struct bl_attn_desc {
   float scale;         /* head_dim^-0.5 */
 } bl_attn_desc;
 int bl_attention_bf16(const bl_attn_desc* d, void* stream);
+/* Prefill attention with the rotary embedding and the KV-cache write fused in (HF apply_rotary_pos_emb +
+ * DynamicCache.update + attention of LlamaAttention.forward in one pass): d->q / d->k / d->v are the UN-rotated thirds of the
+ * fused qkv rows; q and k are rotated at positions pos0 + row while they are loaded (same three bf16 roundings as
+ * bl_rope_kvcache_bf16), the rotated k and v rows are written to k_cache / v_cache [B, H, cache_len, 128]. head_dim 128,
+ * causal, Skv == Sq <= 320. The qkv buffer is left untouched. */
+int bl_attention_rope_bf16(const bl_attn_desc* d, const bl_bf16* cos_tab, const bl_bf16* sin_tab, int32_t pos0, bl_bf16* k_cache,
+                           bl_bf16* v_cache, int32_t cache_len, void* stream);
 /* Training forward: as bl_attention_bf16, and also writes the base-2 log-sum-exp of the scaled scores of every query
  * row to lse[(b*H + h) * pad32(Sq) + i] (fp32; +inf for a row with no visible key) for bl_attention_backward_bf16. */
 int bl_attention_lse_bf16(const bl_attn_desc* d, float* lse, void* stream);

@@ -317,6 +317,64 @@ def test_rope_kvcache(dev):
     assert (kc.cpu()[:, :, :pos0] == 0).all() and (kc.cpu()[:, :, pos0 + S:] == 0).all()
 
 
+@pytest.mark.parametrize("B,H,S,pos0,masked", [(2, 4, 37, 3, False), (2, 32, 288, 0, False), (4, 32, 70, 0, True), (3, 8, 296, 5, True),
+                                                (1, 2, 320, 0, False)])
+def test_attention_rope_fused(dev, B, H, S, pos0, masked):
+    """bl_attention_rope_bf16 == bl_rope_kvcache_bf16 followed by bl_attention_bf16, bit for bit (outputs and caches), and
+    its caches are bit-exact against the oracle's apply_rope."""
+    from bridgelang_amd import ops
+    hd, cache_len = 128, 336
+    D = H * hd
+    qkv = rand_bf16((B * S, 3 * D), 11 + S)
+    cos, sin = R.rope_tables(hd, 512, 10000.0)
+    C_, S_ = dv(cos, dev), dv(sin, dev)
+    mask = None
+    if masked:
+        mask = torch.ones(B, S, dtype=torch.uint8)
+        for i in range(B):
+            mask[i, S - 3 * i:] = 0
+        mask = mask.to(dev)
+    # two-kernel path
+    Q1 = dv(qkv, dev)
+    kc1 = torch.zeros(B, H, cache_len, hd, dtype=torch.bfloat16, device=dev)
+    vc1 = torch.zeros_like(kc1)
+    o1 = torch.zeros(B * S, D, dtype=torch.bfloat16, device=dev)
+    ops.rope_kvcache(Q1, C_, S_, kc1, vc1, B=B, S=S, H=H, head_dim=hd, pos0=pos0)
+    cs = (H * cache_len * hd, cache_len * hd, hd)
+    ops.attention(Q1, kc1[:, :, pos0:], vc1[:, :, pos0:], o1, B=B, H=H, Sq=S, Skv=S, head_dim=hd, q_strides=(S * 3 * D, hd, 3 * D),
+                  k_strides=cs, v_strides=cs, o_strides=(S * D, hd, D), causal=True, key_mask=mask)
+    # fused
+    Q2 = dv(qkv, dev)
+    kc2 = torch.zeros_like(kc1)
+    vc2 = torch.zeros_like(kc1)
+    o2 = torch.zeros_like(o1)
+    ops.attention_rope(Q2, kc2, vc2, o2, C_, S_, B=B, S=S, H=H, head_dim=hd, pos0=pos0, key_mask=mask)
+    assert torch.equal(Q2.cpu(), qkv.to(torch.bfloat16)), "the fused kernel must leave qkv untouched"
+    assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2), "caches differ from bl_rope_kvcache_bf16"
+    t = qkv.view(B, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+    assert torch.equal(kc2.cpu().float()[:, :, pos0:pos0 + S], R.apply_rope(P, t[1], cos, sin, pos0)), "cached k vs oracle"
+    assert torch.equal(vc2.cpu().float()[:, :, pos0:pos0 + S], t[2])
+    assert (kc2.cpu()[:, :, :pos0] == 0).all() and (kc2.cpu()[:, :, pos0 + S:] == 0).all()
+    a, b = o1.view(B, S, D), o2.view(B, S, D)
+    if masked:       # rows of masked-out queries are unspecified
+        for i in range(B):
+            assert torch.equal(a[i, :S - 3 * i], b[i, :S - 3 * i]), f"fused attention differs, b={i}"
+    else:
+        assert torch.equal(a, b), "fused attention differs from the two-kernel path"
+
+
+def test_attention_rope_rejects(dev):
+    from bridgelang_amd import ops, _lib
+    B, H, hd, S = 1, 2, 128, 32
+    D = H * hd
+    qkv = torch.zeros(B * S, 3 * D, dtype=torch.bfloat16, device=dev)
+    kc = torch.zeros(B, H, 40, hd, dtype=torch.bfloat16, device=dev)
+    o = torch.zeros(B * S, D, dtype=torch.bfloat16, device=dev)
+    cos = torch.zeros(64, 64, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(_lib.BridgeLangHipError):       # pos0 + S beyond the cache
+        ops.attention_rope(qkv, kc, kc.clone(), o, cos, cos, B=B, S=S, H=H, head_dim=hd, pos0=9)
+
+
 def test_embed_splice_argmax_im2col_prefix(dev):
     from bridgelang_amd import ops
     B, L, dim, V, npatch = 3, 9, 64, 100, 16
