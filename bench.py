@@ -43,8 +43,9 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--model", default="openvla-7b", choices=["openvla-7b", "openvla-tiny", "prism-13b"])
     ap.add_argument("--no-graph", action="store_true", help="replay the op plan eagerly instead of as one HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
-                    help="2 = overlap batch i's decode with batch i+1's vision+prefill (TwoStagePipeline)")
+    ap.add_argument("--pipeline", type=int, default=7, choices=[1, 2, 7, 8],
+                    help="2 = overlap batch i's decode with batch i+1's vision+prefill (TwoStagePipeline); 7 = StaggeredDecodePipeline "
+                         "(one merged decode iteration over the 6 older batches per step)")
     return ap.parse_args()
 
 
@@ -206,7 +207,20 @@ def main() -> None:
         for _ in range(max(args.warmup, 2)):     # also fills the pipeline
             pipe.step()
         elapsed = timed(pipe.step, args.steps)   # every step completes one batch (submitted one step earlier)
+    elif args.pipeline >= 7:
+        from bridgelang_amd.pipeline import StaggeredDecodePipeline
+        pipe = StaggeredDecodePipeline(w, args.batch, args.prompt_len, split_vision=args.pipeline == 8)
+        for e in pipe.engines:
+            e.set_inputs(ids, pv)
+        if not args.no_graph:
+            pipe.capture()
+        for _ in range(max(args.warmup, pipe.slots)):     # also fills the pipeline
+            pipe.step()
+        elapsed = timed(pipe.step, args.steps)   # every step submits one batch and completes the one submitted 6 steps earlier
+        ids_pipe = pipe.step().clone().cpu()
     ids_out = eng.gen_ids.t().cpu()
+    if args.pipeline >= 7 and rank == 0:
+        pipe_agree = float((ids_pipe == ids_out).all(dim=1).float().mean())
 
     if rank == 0:
         seqs = world * args.batch * args.steps
@@ -230,8 +244,11 @@ def main() -> None:
             "config": {"workload": (f"{dims.name} bf16 inference (BASELINE configs[1]): batch {args.batch} synthetic 224px "
                                     f"frames + {args.prompt_len}-token prompts per GPU, predict_action = vision towers + "
                                     f"projector + Llama prefill S={eng.S} + 6 cached decode steps, greedy"
-                                    + ("; 2 batches in flight (batch i decode overlaps batch i+1 vision+prefill), one "
-                                       "batch completes per step" if args.pipeline == 2 else "")),
+                                    + {1: "", 2: "; 2 batches in flight (batch i decode overlaps batch i+1 vision+prefill), one "
+                                                 "batch completes per step",
+                                       7: "; 7 batches in flight: per step one batch is submitted (vision+prefill) while decode "
+                                          "iteration g of the batch submitted g steps earlier, g = 1..6, runs as ONE merged 96-row "
+                                          "pass over the weights; one batch completes per step"}.get(args.pipeline, "8 in flight")),
                        "batch_per_gpu": args.batch, "prompt_len": args.prompt_len, "seq_len": eng.S,
                        "replicas": world, "hip_graph": not args.no_graph, "pipeline_depth": args.pipeline},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -250,6 +267,8 @@ def main() -> None:
                                                    "ms_per_step": round(elapsed_single / args.steps * 1e3, 3)},
                            "first_ids": ids_out[0].tolist()},
         }
+        if args.pipeline >= 7:   # same inputs in every slot: fraction of sequences whose 7 ids equal the one-batch engine's
+            line["end_to_end"]["staggered_ids_equal_one_batch_engine"] = round(pipe_agree, 4)
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would wait at the barrier)
             line["cpu_baseline"] = cpu_baseline(dims, args.batch, args.prompt_len)
         print(json.dumps(line), flush=True)

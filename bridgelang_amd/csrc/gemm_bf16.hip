@@ -166,6 +166,122 @@ __global__ __launch_bounds__(256) void gemm128_kernel(GemmArgs p) {
 #endif
 }
 
+// ======================================================================================================================
+// tail kernel: BM × BN sub-tiles (128×128, 128×64 or 64×64) of the big kernel's leftover 256×256 tiles, 4 waves (2 × 2),
+// NST-stage LDS-DMA ring with NST-1 K-tiles in flight behind a counted vmcnt and ONE barrier per K-step. The leftover
+// round has at most one workgroup per CU, so nothing else hides the HBM/L2 latency — the two-stage gemm128 loop spent
+// ≈ 3/4 of every K-step waiting there. K order per output = the big kernel's (bit-identical results).
+// ======================================================================================================================
+template <int EPI, int BM, int BN, int NST, int WM = 2>
+__global__ __launch_bounds__(WM * 128) void gemm_tail_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NWAVE = WM * 2, TM = BM / WM, TN = BN / 2, MT = TM / 16, NT = TN / 16;
+  constexpr int APW = BM / 8 / NWAVE, WPW = BN / 8 / NWAVE, LPS = APW + WPW;   // LDS-DMA pieces per wave and stage
+  constexpr int A_BYTES = BM * ROW_BYTES, BUF_BYTES = A_BYTES + BN * ROW_BYTES;
+  constexpr int SUB_N = 256 / BN, SUBS = (256 / BM) * SUB_N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // NST × BUF_BYTES
+
+  // workgroups go to XCDs round-robin: give each XCD (private L2) a contiguous run of sub-tiles, i.e. WHOLE leftover tiles —
+  // with the plain order the SUBS pieces of a tile land on SUBS different L2s and every one of them fetches the same rows
+  const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  int tm, tn;
+  lin_to_tile(p, p.tail_base + lin / SUBS, tm, tn);
+  const int sub = lin % SUBS;
+  const int m0 = tm * 256 + (sub / SUB_N) * BM, n0 = tn * 256 + (sub % SUB_N) * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kt32 = p.K >> 5;
+
+  const unsigned a_bytes = (unsigned)min((long)p.M * p.lda * 2, 0xffffffffL);
+  const unsigned w_bytes = (unsigned)min((long)p.N * p.K * 2, 0xffffffffL);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
+
+  const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
+  static_assert(APW >= 1 && WPW >= 1, "tile too small for the wave count");
+  unsigned voffA[APW], voffW[WPW];
+#pragma unroll
+  for (int j = 0; j < APW; ++j) voffA[j] = (unsigned)(((long)(m0 + (j * NWAVE + wave) * 8 + prow) * p.lda) * 2 + pchunk * 16);
+#pragma unroll
+  for (int j = 0; j < WPW; ++j) {   // weight block b = j*NWAVE + wave: n-tile b >> 1, k-step b & 1
+    const int blk = j * NWAVE + wave;
+    voffW[j] = (unsigned)(((long)(n0 / 16 + (blk >> 1)) * kt32 + (blk & 1)) * 1024 + lane * 16);
+  }
+
+#define BL_STAGE(BUF, KT)                                                                                   \
+  do {                                                                                                      \
+    char* base__ = smem + (BUF) * BUF_BYTES;                                                                \
+    _Pragma("unroll") for (int j = 0; j < APW; ++j) BL_GLDS(rsA, base__ + (j * NWAVE + wave) * 1024, voffA[j], (KT) * 128); \
+    _Pragma("unroll") for (int j = 0; j < WPW; ++j)                                                         \
+        BL_GLDS(rsW, base__ + A_BYTES + (j * NWAVE + wave) * 1024, voffW[j], (KT) * 2048);                  \
+  } while (0)
+
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int c0 = lg ^ (lane & 7);
+  const int offA = (wm * TM + l15) * ROW_BYTES;
+  const int offW = A_BYTES + (wn * NT) * 2048 + lane * 16;   // block (wn*NT + i)*2 + ks
+
+  f32x4_t acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // Branch-free ring: every iteration issues one stage — past the end of K it re-fetches the last K-tile into a slot nobody
+  // reads again — so exactly NST-1 stages are in flight at every wait and the loop body has no control flow (with branches
+  // between the MFMAs the compiler parks the accumulators in VGPRs and copies them to AGPRs around every MFMA).
+  const int nk = p.K / BK;
+#pragma unroll
+  for (int s2 = 0; s2 < NST - 1; ++s2) BL_STAGE(s2, min(s2, nk - 1));
+  static_assert((NST - 2) * LPS <= 63, "counted vmcnt range");
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPS) : "memory");   // K-tile kt landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();      // K-tile kt landed for every wave; every wave is done reading K-tile kt-1
+    const char* base = smem + (kt % NST) * BUF_BYTES;
+    // one wave per SIMD: nothing else covers this wave's issue slots — the next ring slot's LDS-DMA pieces are issued in
+    // the shadow of the MFMAs (sched_group_barrier order below)
+    char* nbase = smem + ((kt + NST - 1) % NST) * BUF_BYTES;     // the slot of K-tile kt-1
+    const int nkt = min(kt + NST - 1, nk - 1);
+#pragma unroll
+    for (int pc = 0; pc < APW; ++pc) BL_GLDS(rsA, nbase + (pc * NWAVE + wave) * 1024, voffA[pc], nkt * 128);
+#pragma unroll
+    for (int jw = 0; jw < WPW; ++jw) BL_GLDS(rsW, nbase + A_BYTES + (jw * NWAVE + wave) * 1024, voffW[jw], nkt * 2048);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int cb = (c0 ^ (ks * 4)) << 4;
+      bf16x8_t wf[NT], af[MT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) wf[i] = *(const bf16x8_t*)(base + offW + i * 2048 + ks * 1024);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) af[j] = *(const bf16x8_t*)(base + offA + j * 16 * ROW_BYTES + cb);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+    constexpr int NMF = 2 * NT * MT, EVERY = NMF / LPS;          // one piece every EVERY MFMAs
+    static_assert(EVERY >= 1, "more DMA pieces than MFMAs");
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (NT + MT), 0);   // all DS reads first
+#pragma unroll
+    for (int pc = 0; pc < LPS; ++pc) {
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             // VMEM read (one LDS-DMA piece)
+      __builtin_amdgcn_sched_group_barrier(0x008, EVERY, 0);         // MFMA
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NMF - EVERY * LPS, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus stages must not outlive the workgroup's LDS allocation
+#undef BL_STAGE
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+      epilogue_store4<EPI>(p, m0 + wm * TM + j * 16 + l15, n0 + wn * TN + i * 16 + lg * 4, acc[i][j]);
+#endif
+}
+
 // out(m, n..n+3) = epilogue(Σ_slices slab[slice][m][n..n+3]) for the split-K form of the 128 kernel
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm128_splitk_reduce_kernel(GemmArgs p) {
@@ -714,6 +830,12 @@ int set_lds_attr() {
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * ROW_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tail_kernel<EPI, 128, 128, 4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * ROW_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tail_kernel<EPI, 128, 64, 4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 192 * ROW_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tail_kernel<EPI, 64, 64, 4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * ROW_BYTES) != hipSuccess ||
         !mid_attr<EPI, 2, 4>() || !mid_attr<EPI, 4, 4>() || !mid_attr<EPI, 5, 4>() || !mid_attr<EPI, 2, 1>() ||
         !mid_attr<EPI, 4, 1>() || !mid_attr<EPI, 5, 1>())
       return BL_E_LAUNCH;
@@ -816,8 +938,16 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (tail != 0 && tail <= 64 && main_tiles > tail && !force) main_tiles = big_tiles - tail; else tail = 0;
     BL_LAUNCH256(main_tiles);
     if (tail) {
+      // leftover 256x256 tiles, cut so that the sub-tiles cover (up to) every CU once
       p.tail_base = main_tiles;
-      hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(tail * 4), dim3(256), LDS128, s, p);
+      static const bool old_tail = getenv("BL_GEMM_OLD_TAIL") != nullptr;   // A/B aid
+      if (old_tail) hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(tail * 4), dim3(256), LDS128, s, p);
+      else if (tail <= 16)
+        hipLaunchKernelGGL((gemm_tail_kernel<EPI, 64, 64, 4>), dim3(tail * 16), dim3(256), 4 * 128 * ROW_BYTES, s, p);
+      else if (tail <= 32)
+        hipLaunchKernelGGL((gemm_tail_kernel<EPI, 128, 64, 4>), dim3(tail * 8), dim3(256), 4 * 192 * ROW_BYTES, s, p);
+      else
+        hipLaunchKernelGGL((gemm_tail_kernel<EPI, 128, 128, 4>), dim3(tail * 4), dim3(256), 4 * 256 * ROW_BYTES, s, p);
     }
   }
 #undef BL_LAUNCH256

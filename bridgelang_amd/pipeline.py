@@ -1,4 +1,6 @@
-"""Two-deep software pipeline over batches for throughput serving.
+"""Software pipelines over batches for throughput serving: `TwoStagePipeline` (two batches in flight) and
+`StaggeredDecodePipeline` (n_new batches in flight, their decode iterations merged into one weight pass per step).
+
 
 A `predict_action` batch has two very different halves: vision + prefill is MFMA-bound (≈ 65 ms at B = 16) but leaves
 CUs idle in partial GEMM rounds and between dependent launches; the 6 cached decode steps are HBM-bound weight streaming
@@ -16,6 +18,7 @@ import torch
 
 from . import ops
 from .engine import OpenVLAEngine
+from .ops import EPI_F32_BF16R, EPI_NONE, EPI_RES, EPI_SWIGLU, Op
 from .weights import VLAWeights
 
 
@@ -69,3 +72,141 @@ class TwoStagePipeline:
         for step in self.engines[k].decode_ops:
             ops.run_all(step)
         return self.engines[k].gen_ids.t()
+
+
+class StaggeredDecodePipeline:
+    """n_new batches in flight, one submitted and one completed per step (continuous batching for a fixed-length decode).
+
+    A cached decode iteration streams all 13.2 GB of Llama weights for B = 16 rows, six times per batch. With one batch
+    submitted per step, the batches submitted 1, 2, … n_new-1 steps ago are exactly at decode iterations 1, 2, … n_new-1:
+    their rows are stacked into ONE (n_new-1)·B-row iteration, so every weight matrix is streamed once per step instead of
+    n_new-1 times (the rows go through the tiled GEMMs; only attention — own KV cache, own position — runs per batch).
+    Per step: vision + projector + prefill of the new batch on one stream ‖ the merged decode iteration on another; the
+    work per step is exactly one batch's full computation, a batch's latency is n_new steps. Slot s of the n_new slots
+    (KV caches, ids, prefill activations = one OpenVLAEngine each) holds the batch submitted at step ≡ s (mod n_new); the
+    n_new slot rotations are captured as n_new HIP graphs.
+
+    Results per sequence equal the plain engine's up to the fp32 summation order of the decode GEMMs (tiled instead of
+    weight-streaming kernel): same tokens unless the top-2 logit gap is inside bf16 noise (tests/test_pipeline_gpu.py).
+    """
+
+    def __init__(self, weights: VLAWeights, batch: int, prompt_len: int, n_new: int = 7, split_vision: bool = False):
+        """split_vision=True adds a third stage: the vision towers + projector of the batch submitted NOW run beside the
+        Llama prefill of the batch submitted one step earlier (n_new + 1 slots, latency n_new + 1 steps)."""
+        if n_new < 2:
+            raise ValueError("StaggeredDecodePipeline needs at least one decode iteration (n_new >= 2)")
+        self.w, self.dims, self.B, self.n_new = weights, weights.dims, batch, n_new
+        self.split_vision = split_vision
+        self.lag = 1 if split_vision else 0         # steps between a batch's submission and its prefill
+        self.slots = n_new + self.lag
+        self.engines = [OpenVLAEngine(weights, batch, prompt_len, n_new) for _ in range(self.slots)]
+        self.device = dev = weights.embed.device
+        d = self.dims
+        G = n_new - 1
+        M = G * batch
+        z = lambda *shape, dtype=torch.bfloat16: torch.zeros(*shape, dtype=dtype, device=dev)
+        self.xd, self.hd, self.aod = z(M, d.llm_dim), z(M, d.llm_dim), z(M, d.llm_dim)
+        self.qkvd, self.actd = z(M, 3 * d.llm_dim), z(M, d.llm_inter)
+        self.logits = z(M, d.vocab, dtype=torch.float32)       # rows (g-1)·B … g·B: decode iteration g of this step
+        self._decode_stream = torch.cuda.Stream(device=dev)
+        self._vision_stream = torch.cuda.Stream(device=dev)
+        self.merged_ops: List[List[Op]] = [self._plan_merged(k) for k in range(self.slots)]
+        self._graphs: List[Optional[torch.cuda.CUDAGraph]] = [None] * self.slots
+        self._tick = 0
+
+    def _plan_merged(self, k: int) -> List[Op]:
+        """Decode iteration g = 1 … n_new-1 of the batch in slot (k - g) mod n_new, all in one pass over the weights
+        (the per-batch steps of OpenVLAEngine._plan_decode, modeling_prismatic.py:325-341, stacked on the row axis)."""
+        d, w, B = self.dims, self.w, self.B
+        D, H, hd = d.llm_dim, d.llm_heads, d.head_dim
+        e0 = self.engines[0]
+        groups = [(g, self.engines[(k - g - self.lag) % self.slots], slice((g - 1) * B, g * B)) for g in range(1, self.n_new)]
+        plan = [ops.embed_splice(e.gen_ids[g - 1].view(B, 1), w.embed, self.xd[r].view(B, 1, D), 0, run=False)
+                for g, e, r in groups]
+        for l, lw in enumerate(w.layers):
+            plan.append(ops.rmsnorm(self.xd, lw.ln1, self.hd, d.rms_eps, run=False))
+            plan.append(ops.gemm(self.hd, lw.qkv_w, self.qkvd, EPI_NONE, run=False))
+            for g, e, r in groups:
+                pos = e.S + g - 1
+                if hd == 128:
+                    plan.append(ops.attention_decode_rope(self.qkvd[r], e.k_cache[l], e.v_cache[l], self.aod[r], e0.cos, e0.sin,
+                                                          B=B, H=H, head_dim=hd, pos=pos, run=False))
+                else:
+                    cs = (H * e.cache_len * hd, e.cache_len * hd, hd)
+                    plan.append(ops.rope_kvcache(self.qkvd[r], e0.cos, e0.sin, e.k_cache[l], e.v_cache[l], B=B, S=1, H=H,
+                                                 head_dim=hd, pos0=pos, run=False))
+                    plan.append(ops.attention_decode(self.qkvd[r], e.k_cache[l], e.v_cache[l], self.aod[r], B=B, H=H,
+                                                     Skv=pos + 1, head_dim=hd, q_strides=(3 * D, hd, 3 * D), k_strides=cs,
+                                                     v_strides=cs, o_strides=(D, hd, D), run=False))
+            plan.append(ops.gemm(self.aod, lw.o_w, self.xd, EPI_RES, res=self.xd, run=False))
+            plan.append(ops.rmsnorm(self.xd, lw.ln2, self.hd, d.rms_eps, run=False))
+            plan.append(ops.gemm(self.hd, lw.gu_w, self.actd, EPI_SWIGLU, run=False))
+            plan.append(ops.gemm(self.actd, lw.down_w, self.xd, EPI_RES, res=self.xd, run=False))
+        plan.append(ops.rmsnorm(self.xd, w.norm, self.hd, d.rms_eps, run=False))
+        plan.append(ops.gemm(self.hd, w.lm_head, self.logits, EPI_F32_BF16R, run=False))
+        plan += [ops.argmax(self.logits[r], e.gen_ids[g], run=False) for g, e, r in groups]
+        return plan
+
+    def _run_tick(self, k: int) -> None:
+        """stage 1 of slot k ‖ the merged decode iteration over the other slots."""
+        e1 = self.engines[k]
+        main = torch.cuda.current_stream()
+        self._decode_stream.wait_stream(main)
+        with torch.cuda.stream(self._decode_stream):
+            ops.run_all(self.merged_ops[k])
+        if self.split_vision:
+            vs, ss = self._vision_stream, e1._side      # both towers fork from the main stream (no nested fork)
+            vs.wait_stream(main)
+            ss.wait_stream(main)
+            with torch.cuda.stream(ss):
+                ops.run_all(e1.siglip_ops)
+            with torch.cuda.stream(vs):
+                ops.run_all(e1.dino_ops)
+                vs.wait_stream(ss)
+                ops.run_all(e1.projector_ops)
+            ops.run_all(self.engines[(k - 1) % self.slots].prefill_ops)
+            main.wait_stream(vs)
+        else:
+            e1.run_vision()
+            ops.run_all(e1.projector_ops + e1.prefill_ops)
+        main.wait_stream(self._decode_stream)
+
+    def capture(self) -> None:
+        for k in range(self.slots):
+            self._run_tick(k)          # eager warm-up (also sets kernel attributes outside capture)
+        torch.cuda.synchronize()
+        for k in range(self.slots):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._run_tick(k)
+            self._graphs[k] = g
+
+    @torch.no_grad()
+    def step(self, input_ids: Optional[torch.Tensor] = None, pixel_values: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Submit a batch (None: re-use the inputs resident in the slot's buffers) and return the [B, n_new] ids of the
+        batch submitted n_new-1 steps earlier, which this step completed (garbage until the pipeline has filled). The
+        returned view is overwritten by the next step() — copy it first."""
+        k = self._tick % self.slots
+        if input_ids is not None:
+            self.engines[k].set_inputs(input_ids, pixel_values)
+        if self._graphs[k] is not None:
+            self._graphs[k].replay()
+        else:
+            self._run_tick(k)
+        self._tick += 1
+        return self.engines[(k + 1) % self.slots].gen_ids.t()
+
+    def flush(self) -> List[torch.Tensor]:
+        """Drain: finish the batches still in flight with each slot's own per-batch plans; returns their ids oldest
+        first (copies)."""
+        out = []
+        for a in range(min(self.slots - 2, self._tick - 1), -1, -1):    # a = steps since the batch was submitted
+            e = self.engines[(self._tick - 1 - a) % self.slots]
+            j = a - self.lag                                            # decode iterations already done (-1: not prefilled)
+            if j < 0:
+                ops.run_all(e.prefill_ops)
+                j = 0
+            for step in e.decode_ops[j:]:
+                ops.run_all(step)
+            out.append(e.gen_ids.t().clone())
+        return out

@@ -176,6 +176,50 @@ def test_graph_and_pipeline_equal_eager_full_size(full, dev):
     assert torch.equal(out_a, eager) and torch.equal(out_b, want_b)
 
 
+@pytest.mark.parametrize("split", [False, True])
+def test_staggered_pipeline_full_size(full, dev, split):
+    """7 (8 with the vision stage split off) batches in flight at 7B width, 96 merged decode rows through the mid-M GEMM:
+    per sequence the merged pass's logits agree with the plain engine's to bf16 noise wherever the prefixes agree, and
+    ids differ only at near ties (random-init weights give flat logits, so near ties are common — the count is printed)."""
+    from bridgelang_amd.pipeline import StaggeredDecodePipeline
+    from test_pipeline_gpu import _check_ids
+    dims, w, eng, ids, pv = full
+    eng._graph = None
+    n = 10
+    batches = [(ids, pv)] + [tuple(t.to(dev) for t in make_inputs(B, L, 10 + s)) for s in range(n - 1)]
+    want, want_lg = [], []
+    for i, p in batches:
+        want.append(eng.generate(i, p).clone().cpu())
+        want_lg.append(eng.logits.clone())
+    pipe = StaggeredDecodePipeline(w, B, L, split_vision=split)
+    for e in pipe.engines:
+        e.set_inputs(ids, pv)
+    pipe.capture()
+    got, diffs, checked, worst = [], 0, 0, 0.0
+    for k, (i, p) in enumerate(batches):
+        out = pipe.step(i, p).clone()
+        if k >= pipe.slots - 1:
+            got.append(out.cpu())
+        for g in range(1, pipe.n_new):       # this step ran decode iteration g of batch j
+            j = k - g - pipe.lag
+            if j < 0:
+                continue
+            have = pipe.engines[j % pipe.slots].gen_ids[:g].t().cpu()
+            a, b = pipe.logits[(g - 1) * B:g * B], want_lg[j][g]
+            for q in range(B):
+                if torch.equal(have[q], want[j][q, :g]):
+                    r = ((a[q] - b[q]).abs().amax() / b[q].abs().amax()).item()
+                    worst, checked = max(worst, r), checked + 1
+    print(f"\nmerged decode (split_vision={split}): {checked} (sequence, iteration) logit rows checked, worst max|dlogit|/scale = {worst:.3g}")
+    assert checked >= n * B * 2 and worst <= 5e-2      # measured 3.6 %: bf16 noise of 32 layers, as in the KV-cache test
+    got += [o.cpu() for o in pipe.flush()]
+    assert len(got) == n
+    for k in range(n):
+        diffs += _check_ids(got[k], want[k], want_lg[k].cpu(), f"batch {k}")
+    print(f"staggered pipeline: {diffs} of {n * B} sequences diverge at a near tie")
+    del pipe
+
+
 def test_kv_cache_consistency_full_size(full, dev):
     """Greedy token t+1 produced by the cached decode must equal the greedy token produced by a fresh prefill over
     prompt + tokens[0..t] (the reference's use_cache=False path, run_openvla_demo.py:43, gives the same ids)."""
