@@ -852,16 +852,28 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   GemmArgs p = a;
   static const char* force = getenv("BL_GEMM_TILE");   // "128" / "256": benchmarking aid
   const int bm = (p.M + 255) / 256, bn = (p.N + 255) / 256, big_tiles = bm * bn;
-  bool big = big_tiles >= CUS && p.K >= 512;
+  // one (partial) round of big tiles beats 1.5+ rounds of the 128 kernel once ≥ ~3/4 of the CUs get a tile (ViT qkv at
+  // B = 16: 204 / 224 tiles, 45 → 39 µs)
+  bool big = big_tiles >= 200 && p.K >= 512;
   if (force) big = force[0] == '2';
   static const bool no_mid = getenv("BL_GEMM_NO_MID") != nullptr;      // A/B aid
   if (p.M <= 320 && p.M > 32 && p.K >= 512 && !force && !no_mid) {
     // every weight byte once: one workgroup per column slab, all rows; 64-column slabs when that already gives ≥ 160
     // workgroups, else 16-column slabs. grid.y slices K only with a workspace (opt-in).
-    const bool wide = (p.N + 63) / 64 >= 160;
-    const int slabs = wide ? (p.N + 63) / 64 : (p.N + 15) / 16, nkm = p.K / BK;
+    const int slabs64 = (p.N + 63) / 64, nkm = p.K / BK;
+    bool wide = slabs64 >= 160;
     int S = 1;
-    if (p.slab && !getenv("BL_GEMM_NO_SPLITK") && slabs < CUS) {
+    static const bool no_split_mid = getenv("BL_GEMM_NO_SPLITK") != nullptr;
+    if (!wide && p.slab && !no_split_mid && slabs64 * 2 <= CUS) {
+      // Every workgroup re-reads ALL M rows of A from L2, so the L2 traffic is (N / slab width) · M · K · 2 B: with a
+      // workspace, narrow layers (N = 4096: 64 slabs of 64 columns) keep the 64-column slabs — a quarter of the activation
+      // traffic of 16-column slabs — and fill the chip by slicing K instead (same slicing for every row: slot-invariant)
+      int S2 = min(8, CUS / slabs64);
+      while (S2 > 1 && (nkm / S2 < 8 || p.slab_bytes < (long)S2 * p.M * p.N * 4)) --S2;
+      if (S2 > 1) { wide = true; S = S2; }
+    }
+    const int slabs = wide ? slabs64 : (p.N + 15) / 16;
+    if (S == 1 && !wide && p.slab && !no_split_mid && slabs < CUS) {
       S = min(8, (CUS + CUS / 2 + slabs - 1) / slabs);
       while (S > 1 && (nkm / S < 8 || p.slab_bytes < (long)S * p.M * p.N * 4)) --S;
     }

@@ -108,6 +108,8 @@ class StaggeredDecodePipeline:
         self.xd, self.hd, self.aod = z(M, d.llm_dim), z(M, d.llm_dim), z(M, d.llm_dim)
         self.qkvd, self.actd = z(M, 3 * d.llm_dim), z(M, d.llm_inter)
         self.logits = z(M, d.vocab, dtype=torch.float32)       # rows (g-1)·B … g·B: decode iteration g of this step
+        # fp32 split-K scratch of the merged decode GEMMs (N = 4096 layers slice K; every row alike → slot-invariant)
+        self.ws = torch.empty(max(32 << 20, 8 * M * d.llm_dim * 4), dtype=torch.uint8, device=dev)
         self._decode_stream = torch.cuda.Stream(device=dev)
         self._vision_stream = torch.cuda.Stream(device=dev)
         self.merged_ops: List[List[Op]] = [self._plan_merged(k) for k in range(self.slots)]
@@ -120,12 +122,13 @@ class StaggeredDecodePipeline:
         d, w, B = self.dims, self.w, self.B
         D, H, hd = d.llm_dim, d.llm_heads, d.head_dim
         e0 = self.engines[0]
+        gm = lambda *a, **kw: ops.gemm(*a, workspace=self.ws, **kw)
         groups = [(g, self.engines[(k - g - self.lag) % self.slots], slice((g - 1) * B, g * B)) for g in range(1, self.n_new)]
         plan = [ops.embed_splice(e.gen_ids[g - 1].view(B, 1), w.embed, self.xd[r].view(B, 1, D), 0, run=False)
                 for g, e, r in groups]
         for l, lw in enumerate(w.layers):
             plan.append(ops.rmsnorm(self.xd, lw.ln1, self.hd, d.rms_eps, run=False))
-            plan.append(ops.gemm(self.hd, lw.qkv_w, self.qkvd, EPI_NONE, run=False))
+            plan.append(gm(self.hd, lw.qkv_w, self.qkvd, EPI_NONE, run=False))
             for g, e, r in groups:
                 pos = e.S + g - 1
                 if hd == 128:
@@ -138,12 +141,12 @@ class StaggeredDecodePipeline:
                     plan.append(ops.attention_decode(self.qkvd[r], e.k_cache[l], e.v_cache[l], self.aod[r], B=B, H=H,
                                                      Skv=pos + 1, head_dim=hd, q_strides=(3 * D, hd, 3 * D), k_strides=cs,
                                                      v_strides=cs, o_strides=(D, hd, D), run=False))
-            plan.append(ops.gemm(self.aod, lw.o_w, self.xd, EPI_RES, res=self.xd, run=False))
+            plan.append(gm(self.aod, lw.o_w, self.xd, EPI_RES, res=self.xd, run=False))
             plan.append(ops.rmsnorm(self.xd, lw.ln2, self.hd, d.rms_eps, run=False))
-            plan.append(ops.gemm(self.hd, lw.gu_w, self.actd, EPI_SWIGLU, run=False))
-            plan.append(ops.gemm(self.actd, lw.down_w, self.xd, EPI_RES, res=self.xd, run=False))
+            plan.append(gm(self.hd, lw.gu_w, self.actd, EPI_SWIGLU, run=False))
+            plan.append(gm(self.actd, lw.down_w, self.xd, EPI_RES, res=self.xd, run=False))
         plan.append(ops.rmsnorm(self.xd, w.norm, self.hd, d.rms_eps, run=False))
-        plan.append(ops.gemm(self.hd, w.lm_head, self.logits, EPI_F32_BF16R, run=False))
+        plan.append(gm(self.hd, w.lm_head, self.logits, EPI_F32_BF16R, run=False))
         plan += [ops.argmax(self.logits[r], e.gen_ids[g], run=False) for g, e, r in groups]
         return plan
 

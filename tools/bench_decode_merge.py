@@ -12,28 +12,32 @@ D, I, V = d.llm_dim, d.llm_inter, d.vocab
 z = lambda *s, dtype=torch.bfloat16: torch.zeros(*s, dtype=dtype, device=dev)
 
 
+ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+
+
 def plan(M, fused_norm):
+    G = (lambda *a, **k: ops.gemm(*a, **k)) if fused_norm else (lambda *a, **k: ops.gemm(*a, workspace=ws, **k))
     x, h, qkv, ao, act = (torch.randn(M, D, device=dev).to(torch.bfloat16), z(M, D), z(M, 3 * D), z(M, D), z(M, I))
     lg = z(M, V, dtype=torch.float32)
     p = []
     for lw in w.layers:
         if fused_norm:
-            p.append(ops.gemm(x, lw.qkv_w, qkv, EPI_NONE, a_norm=(lw.ln1, d.rms_eps), run=False))
+            p.append(G(x, lw.qkv_w, qkv, EPI_NONE, a_norm=(lw.ln1, d.rms_eps), run=False))
         else:
             p.append(ops.rmsnorm(x, lw.ln1, h, d.rms_eps, run=False))
-            p.append(ops.gemm(h, lw.qkv_w, qkv, EPI_NONE, run=False))
-        p.append(ops.gemm(ao, lw.o_w, x, EPI_RES, res=x, run=False))
+            p.append(G(h, lw.qkv_w, qkv, EPI_NONE, run=False))
+        p.append(G(ao, lw.o_w, x, EPI_RES, res=x, run=False))
         if fused_norm:
-            p.append(ops.gemm(x, lw.gu_w, act, EPI_SWIGLU, a_norm=(lw.ln2, d.rms_eps), run=False))
+            p.append(G(x, lw.gu_w, act, EPI_SWIGLU, a_norm=(lw.ln2, d.rms_eps), run=False))
         else:
             p.append(ops.rmsnorm(x, lw.ln2, h, d.rms_eps, run=False))
-            p.append(ops.gemm(h, lw.gu_w, act, EPI_SWIGLU, run=False))
-        p.append(ops.gemm(act, lw.down_w, x, EPI_RES, res=x, run=False))
+            p.append(G(h, lw.gu_w, act, EPI_SWIGLU, run=False))
+        p.append(G(act, lw.down_w, x, EPI_RES, res=x, run=False))
     if fused_norm:
-        p.append(ops.gemm(x, w.lm_head, lg, EPI_F32_BF16R, a_norm=(w.norm, d.rms_eps), run=False))
+        p.append(G(x, w.lm_head, lg, EPI_F32_BF16R, a_norm=(w.norm, d.rms_eps), run=False))
     else:
         p.append(ops.rmsnorm(x, w.norm, h, d.rms_eps, run=False))
-        p.append(ops.gemm(h, w.lm_head, lg, EPI_F32_BF16R, run=False))
+        p.append(G(h, w.lm_head, lg, EPI_F32_BF16R, run=False))
     return p
 
 
@@ -64,6 +68,6 @@ for name, N, K, epi in (("qkv", 3 * D, D, EPI_NONE), ("o", D, D, EPI_RES), ("gat
     xs = torch.randn(M, K, device=dev).to(torch.bfloat16)
     out = z(M, N // 2 if epi == EPI_SWIGLU else N)
     attr = {"qkv": "qkv_w", "o": "o_w", "gate/up": "gu_w", "down": "down_w"}[name]
-    p = [ops.gemm(xs, getattr(lw, attr), out, epi, run=False, **({"res": out} if epi == EPI_RES else {})) for lw in w.layers]
+    p = [ops.gemm(xs, getattr(lw, attr), out, epi, run=False, workspace=ws, **({"res": out} if epi == EPI_RES else {})) for lw in w.layers]
     t = time_plan(p, 10, 1)
     print(f"  M=96 {name:8s} N={N:6d} K={K:6d}: {t / 32 * 1e3:7.1f} us  {N * K * 2 / (t / 32) / 1e6:6.0f} GB/s")
