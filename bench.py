@@ -254,7 +254,7 @@ def main() -> None:
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_note": "avg HBM+Infinity-Cache bytes per bl_gemm_bf16 call over the 4 Llama prefill GEMMs, separate --pmc passes (profiles/pmc_r01/gemm_traffic.json)",
-                         "kernel": "gemm256_kernel + gemm128_kernel tail (per bl_gemm_bf16 call)", "launches_per_step": gemm["launches"],
+                         "kernel": "gemm256s_kernel + gemm_tail_kernel / gemm128_kernel (per bl_gemm_bf16 call)", "launches_per_step": gemm["launches"],
                          "avg_launch_us": round(gemm["ms"] * 1e3 / gemm["launches"], 2),
                          "algorithmic_gflop_per_launch": round(gemm["flops"] / gemm["launches"] / 1e9, 3)},
             "end_to_end": {"algorithmic_tflop_per_seq": round(algo, 3),
