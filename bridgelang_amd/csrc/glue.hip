@@ -255,6 +255,37 @@ __global__ void preprocess_u8_kernel(const uint8_t* frames, int B, int hw, uint1
   }
 }
 
+// One pass of Pillow's 8-bit separable resampling (libImaging/Resample.c ImagingResampleHorizontal_8bpc /
+// ImagingResampleVertical_8bpc — what `TVF.resize(PIL image, BICUBIC)` runs, processing_prismatic.py:133): per output
+// sample ss = 2^21 + Σ_k src[first + k] · coef[k] in int32 (22-bit fixed-point coefficients from the host), result
+// clip8(ss >> 22). The intermediate image between the two passes is uint8, as in Pillow. One thread = one output pixel
+// (3 channels). HORIZONTAL: src [B, lines, in_len, 3] → dst [B, lines, out_len, 3]; else src [B, in_len, lines, 3] →
+// dst [B, out_len, lines, 3].
+template <bool HORIZONTAL>
+__global__ void resample_pass_kernel(const uint8_t* src, uint8_t* dst, int B, int lines, int in_len, int out_len,
+                                     const int* bounds, const int* kk, int ksize) {
+  const long total = (long)B * lines * out_len;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int o, line;
+    long b;
+    if (HORIZONTAL) { o = (int)(i % out_len); line = (int)((i / out_len) % lines); b = i / ((long)out_len * lines); }
+    else { line = (int)(i % lines); o = (int)((i / lines) % out_len); b = i / ((long)out_len * lines); }
+    const int first = bounds[2 * o], n = bounds[2 * o + 1];
+    const int* k = kk + (long)o * ksize;
+    int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+    const long step = HORIZONTAL ? 3 : (long)lines * 3;
+    const uint8_t* p = HORIZONTAL ? src + ((b * lines + line) * in_len + first) * 3 : src + ((b * in_len + first) * lines + line) * 3;
+    for (int x = 0; x < n; ++x, p += step) {
+      const int c = k[x];
+      s0 += p[0] * c; s1 += p[1] * c; s2 += p[2] * c;
+    }
+    uint8_t* q = HORIZONTAL ? dst + ((b * lines + line) * out_len + o) * 3 : dst + ((b * out_len + o) * lines + line) * 3;
+    q[0] = (uint8_t)min(max(s0 >> 22, 0), 255);
+    q[1] = (uint8_t)min(max(s1 >> 22, 0), 255);
+    q[2] = (uint8_t)min(max(s2 >> 22, 0), 255);
+  }
+}
+
 inline int grid_for(long total, int block) {
   long g = (total + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));   // cap at 256 CUs × 8 and grid-stride the rest
@@ -357,6 +388,21 @@ extern "C" int bl_preprocess_u8_bf16(const uint8_t* frames, int32_t B, int32_t h
   if ((((uintptr_t)frames) & 3) || !bl_aligned16(out)) return BL_E_ALIGN;
   hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for((long)B * (hw / 8), 256)), dim3(256), 0, (hipStream_t)stream, frames,
                      B, (int)hw, out, mean_std);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_resample_pass_u8(const uint8_t* src, uint8_t* dst, int32_t B, int32_t lines, int32_t in_len, int32_t out_len,
+                                  int32_t horizontal, const int32_t* bounds, const int32_t* coefs, int32_t ksize, void* stream) {
+  if (!src || !dst || !bounds || !coefs) return BL_E_ARG;
+  if (B <= 0 || lines <= 0 || in_len <= 0 || out_len <= 0 || ksize <= 0) return BL_E_SHAPE;
+  const long total = (long)B * lines * out_len;
+  if (horizontal)
+    hipLaunchKernelGGL(resample_pass_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, B,
+                       lines, in_len, out_len, bounds, coefs, ksize);
+  else
+    hipLaunchKernelGGL(resample_pass_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, B,
+                       lines, in_len, out_len, bounds, coefs, ksize);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

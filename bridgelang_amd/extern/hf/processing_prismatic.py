@@ -5,7 +5,8 @@ Mirrors `PrismaticImageProcessor.apply_transform` / `PrismaticProcessor.__call__
 resize straight to 224×224 with PIL bicubic (what torchvision's functional `resize` does for PIL inputs), centre crop
 (identity at 224), `to_tensor` (uint8 / 255, CHW fp32), normalise with the backbone's own mean/std (DINOv2: ImageNet;
 SigLIP: 0.5/0.5 — timm data_cfg values recorded at convert_openvla_weights_to_hf.py:193-197), stack on the channel axis.
-Runs on the CPU exactly like the reference (a few hundred µs per frame); the device path starts at `pixel_values`.
+`preprocess` runs on the CPU exactly like the reference (a few hundred µs per frame); `preprocess_frames_gpu` is the
+same arithmetic on the device for uint8 frames already in HBM.
 torchvision is not installed here, so bit-exactness against it is unpinned; the arithmetic is the same torch ops.
 """
 from __future__ import annotations
@@ -47,13 +48,16 @@ class PrismaticImageProcessor:
         return torch.vstack(planes)
 
     def preprocess_frames_gpu(self, frames: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """uint8 frames [B, 224, 224, 3] resident on the GPU (already at the model resolution: the resize is then the
-        identity) → pixel_values [B, 6, 224, 224] bf16, bit-identical to `apply_transform(...).to(torch.bfloat16)`.
-        One HBM-bound kernel (bl_preprocess_u8_bf16); frames of any other size go through `preprocess` on the host."""
+        """uint8 RGB frames [B, H, W, 3] resident on the GPU → pixel_values [B, 6, 224, 224] bf16, bit-identical to
+        `apply_transform(PIL frame).to(torch.bfloat16)`: Pillow's 8-bit bicubic resize as two HBM-bound passes
+        (bl_resample_pass_u8; skipped for frames already at the model resolution), then to_tensor + both normalisations +
+        channel stack in one kernel (bl_preprocess_u8_bf16)."""
         from ... import ops
         (_, h, w) = self.input_sizes[0]
-        if frames.shape[1:3] != (h, w) or len(self.means) != 2:
-            raise ValueError(f"preprocess_frames_gpu needs frames at the model resolution {h}x{w} and the fused backbone")
+        if len(self.means) != 2 or any(tuple(sz) != (3, h, w) for sz in self.input_sizes):
+            raise ValueError("preprocess_frames_gpu serves the fused backbone with equal input sizes")
+        if frames.shape[1:3] != (h, w):
+            frames = ops.resize_bicubic_u8(frames, h, w)
         key = frames.device
         if getattr(self, "_mean_std", None) is None or self._mean_std.device != key:
             flat = [v for m in self.means for v in m] + [v for s_ in self.stds for v in s_]

@@ -7,6 +7,9 @@ under HIP-graph capture), so steady-state host cost is one ctypes call per kerne
 """
 from __future__ import annotations
 
+import functools
+import math
+
 import ctypes as C
 from typing import Optional, Sequence, Tuple
 
@@ -17,7 +20,7 @@ from ._lib import (AttnDesc, GemmDesc, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EP
                    EPI_RES, EPI_SWIGLU)
 
 __all__ = ["Op", "gemm", "pack_weight", "unpack_weight", "cross_entropy", "layernorm", "rmsnorm", "attention", "attention_rope", "attention_decode", "attention_decode_rope", "skinny_supported", "rope_kvcache", "embed_splice",
-           "argmax", "im2col_patch14", "preprocess_u8", "write_prefix_tokens", "fill_synth", "run_all",
+           "argmax", "im2col_patch14", "preprocess_u8", "resample_coeffs", "resize_bicubic_u8", "write_prefix_tokens", "fill_synth", "run_all",
            "EPI_NONE", "EPI_BIAS", "EPI_BIAS_GELU", "EPI_BIAS_RES", "EPI_RES", "EPI_SWIGLU", "EPI_F32", "EPI_F32_BF16R"]
 
 
@@ -371,6 +374,80 @@ def preprocess_u8(frames: torch.Tensor, mean_std: torch.Tensor, out: torch.Tenso
     if run:
         op.run()
     return op
+
+
+def _bicubic(x: float) -> float:
+    """Pillow's bicubic kernel (a = -0.5, support 2)."""
+    a = -0.5
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+@functools.lru_cache(maxsize=64)
+def resample_coeffs(in_size: int, out_size: int):
+    """Pillow's coefficient table for one axis of an 8-bit bicubic resize (libImaging/Resample.c precompute_coeffs +
+    normalize_coeffs_8bpc, whole-image box): (bounds int32 [out, 2] = first tap / tap count, coefs int32 [out, ksize],
+    ksize). Doubles throughout, in Pillow's operation order; 22-bit fixed point, rounded half away from zero."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = torch.zeros(out_size, 2, dtype=torch.int32)
+    coefs = torch.zeros(out_size, ksize, dtype=torch.int32)
+    inv = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [_bicubic((x + xmin - center + 0.5) * inv) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        if ww != 0.0:
+            w = [v / ww for v in w]
+        bounds[xx, 0], bounds[xx, 1] = xmin, xmax
+        for x, v in enumerate(w):
+            coefs[xx, x] = int(-0.5 + v * (1 << 22)) if v < 0 else int(0.5 + v * (1 << 22))
+    return bounds, coefs, ksize
+
+
+_COEF_DEV: dict = {}
+
+
+def resize_bicubic_u8(frames: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
+    """uint8 frames [B, H, W, 3] on the GPU → [B, out_h, out_w, 3], bit-identical to PIL `Image.resize((out_w, out_h),
+    BICUBIC)` per frame: horizontal pass, uint8 intermediate, vertical pass (a pass whose size does not change is
+    skipped, as in Pillow)."""
+    lib = _lib.load()
+    if frames.dtype != torch.uint8 or not frames.is_cuda or not frames.is_contiguous() or frames.dim() != 4 or frames.shape[-1] != 3:
+        raise TypeError("resize_bicubic_u8: frames must be a contiguous CUDA/HIP uint8 tensor [B, H, W, 3]")
+    B, H, W, _ = frames.shape
+    cur = frames
+
+    def tables(n_in, n_out):
+        key = (n_in, n_out, frames.device)
+        if key not in _COEF_DEV:
+            b, c, ks = resample_coeffs(n_in, n_out)
+            _COEF_DEV[key] = (b.to(frames.device), c.to(frames.device), ks)
+        return _COEF_DEV[key]
+
+    if W != out_w:
+        b, c, ks = tables(W, out_w)
+        dst = torch.empty(B, H, out_w, 3, dtype=torch.uint8, device=frames.device)
+        Op("bl_resample_pass_u8", lib.bl_resample_pass_u8, (cur.data_ptr(), dst.data_ptr(), B, H, W, out_w, 1, b.data_ptr(),
+                                                             c.data_ptr(), ks), (cur, dst, b, c)).run()
+        cur = dst
+    if H != out_h:
+        b, c, ks = tables(H, out_h)
+        dst = torch.empty(B, out_h, out_w, 3, dtype=torch.uint8, device=frames.device)
+        Op("bl_resample_pass_u8", lib.bl_resample_pass_u8, (cur.data_ptr(), dst.data_ptr(), B, out_w, H, out_h, 0, b.data_ptr(),
+                                                             c.data_ptr(), ks), (cur, dst, b, c)).run()
+        cur = dst
+    return cur
 
 
 def fill_synth(dst: torch.Tensor, seed: int, mean: float, scale: float, *, rows: Optional[int] = None,

@@ -277,9 +277,16 @@ int bl_embed_backward_bf16(const int64_t* ids, int32_t B, int32_t L, const bl_bf
 /* Frames already at the model resolution: uint8 [B, H, W, 3] → pixel_values [B, 6, H, W] bf16 = to_tensor + the two
  * normalisations of PrismaticImageProcessor.apply_transform (processing_prismatic.py:128-145; DINOv2 ImageNet mean/std,
  * SigLIP 0.5/0.5) in its fp32 operation order, channel-stacked, rounded to bf16 as the call sites do
- * (`.to(torch.bfloat16)`). mean_std: 12 device floats = mean[6] | std[6]. H*W % 8 == 0. (Resizing stays on the host.) */
+ * (`.to(torch.bfloat16)`). mean_std: 12 device floats = mean[6] | std[6]. H*W % 8 == 0. (Resize first: bl_resample_pass_u8.) */
 int bl_preprocess_u8_bf16(const uint8_t* frames, int32_t B, int32_t height, int32_t width, const float* mean_std, bl_bf16* out,
                           void* stream);
+/* One pass of the PIL resize behind `TVF.resize(img, size, BICUBIC)` (processing_prismatic.py:133; Pillow
+ * libImaging/Resample.c, 8 bits per channel): out = clip8((2^21 + Σ_k src[first + k]·coef[k]) >> 22) with the host's
+ * 22-bit fixed-point coefficient table coefs [out_len, ksize] and bounds [out_len, 2] = (first, count).
+ * horizontal != 0: src [B, lines, in_len, 3] → dst [B, lines, out_len, 3]; else src [B, in_len, lines, 3] →
+ * dst [B, out_len, lines, 3]. uint8 RGB, packed. Bit-exact against Pillow (tests/test_ops_gpu.py). */
+int bl_resample_pass_u8(const uint8_t* src, uint8_t* dst, int32_t B, int32_t lines, int32_t in_len, int32_t out_len,
+                        int32_t horizontal, const int32_t* bounds, const int32_t* coefs, int32_t ksize, void* stream);
 /* pixel_values [B, 6, 224, 224] bf16 (processing_prismatic.py:128-145 layout) → 14x14 patch rows for one tower:
  * out[b*256 + py*16 + px, c*196 + i*14 + j] = pixel_values[b, chan0 + c, py*14 + i, px*14 + j]; columns 588..ld-1
  * are zeroed (K padded to a multiple of 64 for the patch-embed GEMM; timm PatchEmbed conv flattening order). */

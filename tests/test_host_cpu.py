@@ -167,3 +167,20 @@ def test_registries_and_checkpoint_naming():
     assert hf_to_prismatic("language_model.lm_head.weight") == ("llm_backbone", "llm.lm_head.weight")
     sd = {n: torch.zeros(1) for n in names}
     assert set(from_model_state_dicts(to_model_state_dicts(sd, ["vision_backbone", "projector", "llm_backbone"]))) == set(names)
+
+
+@pytest.mark.parametrize("H,W", [(256, 256), (480, 640), (100, 300), (224, 500), (300, 224), (128, 128), (224, 224), (1080, 1920)])
+def test_resample_coefficient_tables_match_pillow(H, W):
+    """ops.resample_coeffs (the host half of bl_resample_pass_u8) + the numpy restatement of the two 8-bit passes give
+    Pillow's bicubic resize bit for bit (down- and up-sampling, one-axis-only cases, the identity)."""
+    from bridgelang_amd import ops
+    from oracle import resample as RS
+    rng = np.random.default_rng(H * 10007 + W)
+    frames = rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+    frames[1, : H // 2] = 255                      # a hard edge: bicubic over/undershoot hits the clip8 path
+    frames[1, H // 2:] = 0
+    tw = None if W == 224 else tuple(t.numpy() for t in ops.resample_coeffs(W, 224)[:2])
+    th = None if H == 224 else tuple(t.numpy() for t in ops.resample_coeffs(H, 224)[:2])
+    got = RS.two_pass(frames, tw, th)
+    want = RS.pil_resize(frames, 224, 224)
+    assert got.shape == want.shape and np.array_equal(got, want)

@@ -423,6 +423,27 @@ def test_preprocess_uint8_frames_bit_exact(dev):
     assert got.shape == (3, 6, 224, 224) and torch.equal(got.cpu(), ref)
 
 
+@pytest.mark.parametrize("H,W", [(256, 256), (480, 640), (100, 300), (224, 500), (300, 224), (128, 96), (720, 1280)])
+def test_resize_bicubic_frames_bit_exact(dev, H, W):
+    """bl_resample_pass_u8 (horizontal + vertical 8-bit passes) ≡ Pillow's bicubic `Image.resize` bit for bit, and the
+    whole GPU frame path ≡ the host image processor (resize → to_tensor → dual normalise → stack → bf16)."""
+    from PIL import Image
+    from bridgelang_amd import ops
+    from bridgelang_amd.extern.hf.processing_prismatic import PrismaticImageProcessor
+    from oracle import resample as RS
+    rng = np.random.default_rng(H * 10007 + W)
+    frames = rng.integers(0, 256, (3, H, W, 3), dtype=np.uint8)
+    frames[1, : H // 2] = 255                      # hard edges: over/undershoot must clip exactly as clip8 does
+    frames[1, H // 2:] = 0
+    frames[2, :, ::2] = 0
+    F = torch.from_numpy(frames).to(dev)
+    got = ops.resize_bicubic_u8(F, 224, 224)
+    assert torch.equal(got.cpu(), torch.from_numpy(RS.pil_resize(frames, 224, 224)))
+    ip = PrismaticImageProcessor()
+    ref = torch.stack([ip.apply_transform(Image.fromarray(f)) for f in frames]).to(torch.bfloat16)
+    assert torch.equal(ip.preprocess_frames_gpu(F).cpu(), ref)
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(288, 12288, 4096, "none"), (288, 4096, 1024, "res"), (261, 1024, 4096, "res"), (256, 4352, 1152, "gelu"),
                                        (100, 192, 512, "gelu"), (33, 64, 1536, "none"), (320, 3072, 1536, "swiglu"), (288, 256, 1088, "res")])
 def test_gemm_mid_rows(dev, M, N, K, epi):
