@@ -112,6 +112,7 @@ class StaggeredDecodePipeline:
         self.ws = torch.empty(max(32 << 20, 8 * M * d.llm_dim * 4), dtype=torch.uint8, device=dev)
         self._decode_stream = torch.cuda.Stream(device=dev)
         self._vision_stream = torch.cuda.Stream(device=dev)
+        self._main_stream = torch.cuda.Stream(device=dev)    # capture stream (stream priorities were tried: no effect)
         self.merged_ops: List[List[Op]] = [self._plan_merged(k) for k in range(self.slots)]
         self._graphs: List[Optional[torch.cuda.CUDAGraph]] = [None] * self.slots
         self._tick = 0
@@ -180,7 +181,7 @@ class StaggeredDecodePipeline:
         torch.cuda.synchronize()
         for k in range(self.slots):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=self._main_stream):
                 self._run_tick(k)
             self._graphs[k] = g
 
