@@ -438,14 +438,32 @@ __global__ __launch_bounds__(512) void attn_seq_kernel(AttnArgs p, int s_pad) {
 // every wave (Skv ≤ 2048 floats), the PV partials of the 4 waves are summed through LDS.
 // ROPE = true additionally rotates q and the new token's k at position `pos`, appends k', v to cache row `pos`
 // and treats that row as the last key (HF apply_rotary_pos_emb + DynamicCache.update, fused).
-template <bool ROPE>
+// Several decode iterations in one launch (StaggeredDecodePipeline): group g = B consecutive rows of q / o with their own
+// KV caches and position. By-value kernel argument, indexed with the (uniform) group id.
+struct DecodeGroups {
+  uint16_t* k[8]; uint16_t* v[8]; int pos[8];
+};
+
+template <bool ROPE, bool GROUPED = false>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p, const uint16_t* kn, const uint16_t* vn,
-                                                          const uint16_t* cos_tab, const uint16_t* sin_tab, int pos) {
+                                                          const uint16_t* cos_tab, const uint16_t* sin_tab, int pos,
+                                                          DecodeGroups gr) {
   constexpr int MAXKV = 2048;   // head_dim is fixed at 128 (16 lanes × 16 B per row)
   __shared__ float sc[MAXKV];
   __shared__ float part[4][128];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int bh = blockIdx.x;
+  int bh = blockIdx.x;
+  if constexpr (GROUPED) {
+    const int per = p.B * p.H, g = bh / per;
+    bh -= g * per;
+    p.k = gr.k[g]; p.v = gr.v[g];
+    pos = gr.pos[g];
+    p.Skv = pos + 1;
+    const long roff = (long)g * p.B * p.q_bs;
+    p.q += roff; kn += roff; vn += roff;
+    p.o += (long)g * p.B * p.o_bs;
+    if (p.mask) p.mask += (long)g * p.B * p.mask_bs;
+  }
   const int b = bh / p.H, h = bh - b * p.H;
   const int ks = lane >> 4, dc = lane & 15;
   const long qoff = (long)b * p.q_bs + (long)h * p.q_hs;
@@ -674,7 +692,8 @@ extern "C" int bl_attention_decode_bf16(const bl_attn_desc* d, void* stream) {
   if (d->head_dim != 128 || d->Sq != 1 || d->Skv > 2048) return BL_E_SHAPE;
   if (((uintptr_t)d->o) & 15) return BL_E_ALIGN;
   hipLaunchKernelGGL((attn_decode_kernel<false>), dim3(d->B * d->H), dim3(256), 0, (hipStream_t)stream, a,
-                     (const uint16_t*)nullptr, (const uint16_t*)nullptr, (const uint16_t*)nullptr, (const uint16_t*)nullptr, 0);
+                     (const uint16_t*)nullptr, (const uint16_t*)nullptr, (const uint16_t*)nullptr, (const uint16_t*)nullptr, 0,
+                     DecodeGroups{});
   BL_CHECK_LAUNCH();
   return BL_OK;
 }
@@ -689,7 +708,33 @@ extern "C" int bl_attention_decode_rope_bf16(const bl_attn_desc* d, const bl_bf1
   if ((((uintptr_t)d->o) & 15) || !bl_aligned16(cos_tab) || !bl_aligned16(sin_tab)) return BL_E_ALIGN;
   const long D = (long)d->H * d->head_dim;   // q / k_new / v_new are the three thirds of the fused qkv row
   hipLaunchKernelGGL((attn_decode_kernel<true>), dim3(d->B * d->H), dim3(256), 0, (hipStream_t)stream, a, d->q + D,
-                     d->q + 2 * D, cos_tab, sin_tab, pos);
+                     d->q + 2 * D, cos_tab, sin_tab, pos, DecodeGroups{});
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_attention_decode_rope_grouped_bf16(const bl_attn_desc* d, const bl_bf16* cos_tab, const bl_bf16* sin_tab,
+                                                     int32_t n_groups, bl_bf16* const* k_caches, bl_bf16* const* v_caches,
+                                                     const int32_t* pos, void* stream) {
+  if (!d || !d->q || !d->o || !cos_tab || !sin_tab || !k_caches || !v_caches || !pos) return BL_E_ARG;
+  if (n_groups < 1 || n_groups > 8) return BL_E_SHAPE;
+  bl_attn_desc d0 = *d;                       // validate strides / alignment with group 0's caches in place of k / v
+  d0.k = k_caches[0]; d0.v = v_caches[0]; d0.Skv = pos[0] + 1;
+  AttnArgs a;
+  const int rc = fill_args(&d0, a);
+  if (rc != BL_OK) return rc;
+  DecodeGroups gr{};
+  for (int g = 0; g < n_groups; ++g) {
+    if (!k_caches[g] || !v_caches[g]) return BL_E_ARG;
+    if (pos[g] < 0 || pos[g] + 1 > 2048) return BL_E_SHAPE;
+    if (!bl_aligned16(k_caches[g]) || !bl_aligned16(v_caches[g])) return BL_E_ALIGN;
+    gr.k[g] = k_caches[g]; gr.v[g] = v_caches[g]; gr.pos[g] = pos[g];
+  }
+  if (d->head_dim != 128 || d->Sq != 1) return BL_E_SHAPE;
+  if ((((uintptr_t)d->o) & 15) || !bl_aligned16(cos_tab) || !bl_aligned16(sin_tab)) return BL_E_ALIGN;
+  const long D = (long)d->H * d->head_dim;
+  hipLaunchKernelGGL((attn_decode_kernel<true, true>), dim3(n_groups * d->B * d->H), dim3(256), 0, (hipStream_t)stream, a,
+                     d->q + D, d->q + 2 * D, cos_tab, sin_tab, 0, gr);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

@@ -19,7 +19,7 @@ from . import _lib
 from ._lib import (AttnDesc, GemmDesc, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_F32, EPI_F32_BF16R, EPI_NONE,
                    EPI_RES, EPI_SWIGLU)
 
-__all__ = ["Op", "gemm", "pack_weight", "unpack_weight", "cross_entropy", "layernorm", "rmsnorm", "attention", "attention_rope", "attention_decode", "attention_decode_rope", "skinny_supported", "rope_kvcache", "embed_splice",
+__all__ = ["Op", "gemm", "pack_weight", "unpack_weight", "cross_entropy", "layernorm", "rmsnorm", "attention", "attention_rope", "attention_decode", "attention_decode_rope", "attention_decode_rope_grouped", "skinny_supported", "rope_kvcache", "embed_splice",
            "argmax", "im2col_patch14", "preprocess_u8", "resample_coeffs", "resize_bicubic_u8", "write_prefix_tokens", "fill_synth", "run_all",
            "EPI_NONE", "EPI_BIAS", "EPI_BIAS_GELU", "EPI_BIAS_RES", "EPI_RES", "EPI_SWIGLU", "EPI_F32", "EPI_F32_BF16R"]
 
@@ -356,6 +356,37 @@ def write_prefix_tokens(prefix: torch.Tensor, x: torch.Tensor, B: int, T: int, r
     n_prefix, dim = prefix.shape
     op = Op("bl_write_prefix_tokens_bf16", lib.bl_write_prefix_tokens_bf16,
             (_bf16(prefix, "prefix").data_ptr(), n_prefix, dim, _bf16(x, "x").data_ptr(), B, T), (prefix, x))
+    if run:
+        op.run()
+    return op
+
+
+def attention_decode_rope_grouped(qkv: torch.Tensor, k_caches: Sequence[torch.Tensor], v_caches: Sequence[torch.Tensor],
+                                  o: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, *, B: int, H: int, head_dim: int,
+                                  pos: Sequence[int], run: bool = True) -> Op:
+    """len(pos) decode iterations of different batches in one launch: rows g*B.. of qkv [G*B, 3*H*hd] / o [G*B, H*hd] use
+    caches k_caches[g] / v_caches[g] and position pos[g] (bl_attention_decode_rope_grouped_bf16)."""
+    lib = _lib.load()
+    G, D = len(pos), H * head_dim
+    if not (1 <= G <= 8) or len(k_caches) != G or len(v_caches) != G:
+        raise ValueError("attention_decode_rope_grouped: 1..8 groups, one cache pair and position each")
+    for t, n in [(qkv, "qkv"), (cos, "cos"), (sin, "sin")] + [(t, "cache") for t in list(k_caches) + list(v_caches)]:
+        _bf16(t, n)
+        if not t.is_contiguous():
+            raise ValueError(f"attention_decode_rope_grouped: {n} must be contiguous")
+    cache_len = k_caches[0].shape[2]
+    if any(tuple(t.shape) != tuple(k_caches[0].shape) for t in list(k_caches) + list(v_caches)):
+        raise ValueError("attention_decode_rope_grouped: all caches must share one shape")
+    if max(pos) >= cache_len or max(pos) >= cos.shape[0] or qkv.shape[0] != G * B or o.shape[0] != G * B:
+        raise ValueError("attention_decode_rope_grouped: position outside the cache / rope table, or row count != G*B")
+    cs = (H * cache_len * head_dim, cache_len * head_dim, head_dim)
+    d = _attn_desc(qkv, k_caches[0], v_caches[0], o, B, H, 1, pos[0] + 1, head_dim, (3 * D, head_dim, 3 * D), cs, cs,
+                   (D, head_dim, D), False, head_dim ** -0.5, None)
+    kp = (C.c_void_p * G)(*[t.data_ptr() for t in k_caches])
+    vp = (C.c_void_p * G)(*[t.data_ptr() for t in v_caches])
+    pp = (C.c_int32 * G)(*[int(x) for x in pos])
+    op = Op("bl_attention_decode_rope_grouped_bf16", lib.bl_attention_decode_rope_grouped_bf16,
+            (C.byref(d), cos.data_ptr(), sin.data_ptr(), G, kp, vp, pp), (d, qkv, o, cos, sin, kp, vp, pp, list(k_caches), list(v_caches)))
     if run:
         op.run()
     return op

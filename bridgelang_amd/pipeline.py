@@ -130,8 +130,15 @@ class StaggeredDecodePipeline:
         for l, lw in enumerate(w.layers):
             plan.append(ops.rmsnorm(self.xd, lw.ln1, self.hd, d.rms_eps, run=False))
             plan.append(gm(self.hd, lw.qkv_w, self.qkvd, EPI_NONE, run=False))
+            grouped = hd == 128 and len(groups) <= 8
+            if grouped:     # all decode iterations' attention in one launch
+                plan.append(ops.attention_decode_rope_grouped(
+                    self.qkvd, [e.k_cache[l] for _, e, _ in groups], [e.v_cache[l] for _, e, _ in groups], self.aod,
+                    e0.cos, e0.sin, B=B, H=H, head_dim=hd, pos=[e.S + g - 1 for g, e, _ in groups], run=False))
             for g, e, r in groups:
                 pos = e.S + g - 1
+                if grouped:
+                    continue
                 if hd == 128:
                     plan.append(ops.attention_decode_rope(self.qkvd[r], e.k_cache[l], e.v_cache[l], self.aod[r], e0.cos, e0.sin,
                                                           B=B, H=H, head_dim=hd, pos=pos, run=False))

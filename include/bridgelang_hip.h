@@ -156,6 +156,13 @@ int bl_rope_bf16(bl_bf16* qkv, int64_t ld, int32_t B, int32_t S, int32_t H, int3
  * are written to cache row `pos` of d->k / d->v, and attention runs over keys 0..pos (d->Skv must equal pos + 1). */
 int bl_attention_decode_rope_bf16(const bl_attn_desc* d, const bl_bf16* cos_tab, const bl_bf16* sin_tab, int32_t pos,
                                   void* stream);
+/* n_groups (<= 8) decode iterations of DIFFERENT batches in one launch (continuous batching, pipeline.py): rows
+ * g*B .. (g+1)*B-1 of the fused qkv / output buffers belong to group g, which has its own KV caches
+ * k_caches[g] / v_caches[g] ([B, H, cache_len, 128], strides from d->k_* / d->v_*) and position pos[g]. The three arrays
+ * are HOST arrays read at call time. d->k / d->v / d->Skv are ignored. Per group identical to
+ * bl_attention_decode_rope_bf16. */
+int bl_attention_decode_rope_grouped_bf16(const bl_attn_desc* d, const bl_bf16* cos_tab, const bl_bf16* sin_tab, int32_t n_groups,
+                                          bl_bf16* const* k_caches, bl_bf16* const* v_caches, const int32_t* pos, void* stream);
 
 /* ---- Llama glue -------------------------------------------------------------------------------------------- */
 /* Half-split RoPE (HF apply_rotary_pos_emb) on the q and k thirds of a fused qkv buffer [B*S, 3*H*hd], bf16 cos/sin

@@ -296,6 +296,31 @@ def test_attention_decode(dev, Skv):
     close_bf16(o, ref, "decode attention", rtol=2 ** -5, atol_scale=2 ** -7, min_exact=0.55)
 
 
+def test_attention_decode_rope_grouped(dev):
+    """One grouped launch ≡ one bl_attention_decode_rope_bf16 launch per group, bit for bit (outputs and cache rows)."""
+    from bridgelang_amd import ops
+    B, H, hd, cache_len, G = 3, 4, 128, 320, 6
+    D = H * hd
+    cos, sin = R.rope_tables(hd, 512, 10000.0)
+    C_, S_ = dv(cos, dev), dv(sin, dev)
+    qkv = dv(rand_bf16((G * B, 3 * D), 21), dev)
+    pos = [288 + g for g in range(G)]
+    kc = [dv(rand_bf16((B, H, cache_len, hd), 30 + g), dev) for g in range(G)]
+    vc = [dv(rand_bf16((B, H, cache_len, hd), 40 + g), dev) for g in range(G)]
+    kc2, vc2 = [t.clone() for t in kc], [t.clone() for t in vc]
+    o1 = torch.zeros(G * B, D, dtype=torch.bfloat16, device=dev)
+    o2 = torch.zeros_like(o1)
+    for g in range(G):
+        r = slice(g * B, (g + 1) * B)
+        ops.attention_decode_rope(qkv[r], kc[g], vc[g], o1[r], C_, S_, B=B, H=H, head_dim=hd, pos=pos[g])
+    ops.attention_decode_rope_grouped(qkv, kc2, vc2, o2, C_, S_, B=B, H=H, head_dim=hd, pos=pos)
+    assert torch.equal(o1, o2)
+    for g in range(G):
+        assert torch.equal(kc[g], kc2[g]) and torch.equal(vc[g], vc2[g])
+    with pytest.raises(ValueError):
+        ops.attention_decode_rope_grouped(qkv, kc2, vc2, o2, C_, S_, B=B, H=H, head_dim=hd, pos=[320] * G)
+
+
 # ---- Llama glue -----------------------------------------------------------------------------------------------------
 def test_rope_kvcache(dev):
     from bridgelang_amd import ops
