@@ -176,16 +176,23 @@ class OpenVLAForActionPrediction(PrismaticForConditionalGeneration):
     def predict_action(self, input_ids: Optional[torch.LongTensor] = None, unnorm_key: Optional[str] = None,
                        **kwargs: Any) -> np.ndarray:
         """ids → 7 greedy action tokens → bin centres → un-normalised 7-DoF action (reference :506-536)."""
-        input_ids = input_ids.to(self.device)
-        if not torch.all(input_ids[:, -1] == 29871):
-            tail = torch.full((input_ids.shape[0], 1), 29871, dtype=torch.long, device=self.device)
-            input_ids = torch.cat((input_ids, tail), dim=1)
-            if kwargs.get("attention_mask") is not None:
-                m = kwargs["attention_mask"].to(self.device)
-                kwargs["attention_mask"] = torch.cat((m, torch.ones_like(m[:, :1])), dim=1)
+        input_ids = self.with_empty_token(input_ids.to(self.device))
+        if kwargs.get("attention_mask") is not None and kwargs["attention_mask"].shape[1] != input_ids.shape[1]:
+            m = kwargs["attention_mask"].to(self.device)
+            kwargs["attention_mask"] = torch.cat((m, torch.ones_like(m[:, :1])), dim=1)
         n = self.get_action_dim(unnorm_key)
         generated = self.generate(input_ids, max_new_tokens=n, **kwargs)
-        token_ids = generated[:, -n:].cpu().numpy()
+        return self.actions_from_token_ids(generated[:, -n:].cpu().numpy(), unnorm_key)
+
+    def with_empty_token(self, input_ids: torch.LongTensor) -> torch.LongTensor:
+        """Append the special empty token 29871 the Llama tokenizer would have put after "Out:" (reference :510-515)."""
+        if torch.all(input_ids[:, -1] == 29871):
+            return input_ids
+        tail = torch.full((input_ids.shape[0], 1), 29871, dtype=torch.long, device=input_ids.device)
+        return torch.cat((input_ids, tail), dim=1)
+
+    def actions_from_token_ids(self, token_ids: np.ndarray, unnorm_key: Optional[str] = None) -> np.ndarray:
+        """Generated action token ids [B, n] → un-normalised actions (reference :520-536)."""
         discretized = np.clip(self.vocab_size - token_ids - 1, a_min=0, a_max=self.bin_centers.shape[0] - 1)
         normalized = self.bin_centers[discretized]
         stats = self.get_action_stats(unnorm_key)

@@ -12,7 +12,7 @@ Each of the two stage pairings is captured once as a HIP graph with fork/join st
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List, Optional, Sequence
 
 import torch
 
@@ -207,12 +207,17 @@ class StaggeredDecodePipeline:
         self._tick += 1
         return self.engines[(k + 1) % self.slots].gen_ids.t()
 
-    def flush(self) -> List[torch.Tensor]:
+    def flush(self, ticks: Optional[Sequence[int]] = None) -> List[Optional[torch.Tensor]]:
         """Drain: finish the batches still in flight with each slot's own per-batch plans; returns their ids oldest
-        first (copies)."""
-        out = []
+        first (copies), one entry per step of the last `slots - 1` steps. `ticks`: finish only the batches submitted at
+        these step indices (None entries for the others) — a server that already answered the older slots skips them."""
+        out: List[Optional[torch.Tensor]] = []
         for a in range(min(self.slots - 2, self._tick - 1), -1, -1):    # a = steps since the batch was submitted
-            e = self.engines[(self._tick - 1 - a) % self.slots]
+            tick = self._tick - 1 - a
+            if ticks is not None and tick not in ticks:
+                out.append(None)
+                continue
+            e = self.engines[tick % self.slots]
             j = a - self.lag                                            # decode iterations already done (-1: not prefilled)
             if j < 0:
                 ops.run_all(e.prefill_ops)

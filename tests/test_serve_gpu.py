@@ -57,3 +57,49 @@ def test_act_server_matches_predict_action(dev):
     assert max(server.batch_sizes) >= 2
     assert client.post("/act", json={"instruction": "no image"}).json() == "error"
     server.close()
+
+
+def test_act_server_throughput_mode(dev):
+    """pipeline_batch=B: requests ride the StaggeredDecodePipeline (a batch per tick, merged decode of the older batches,
+    immediate drain when the queue runs dry). Every request is answered with its own sequence's action; answers equal the
+    plain engine's except at near ties of the synthetic model (other decode GEMM kernel, see test_pipeline_gpu.py)."""
+    from PIL import Image
+    from bridgelang_amd import serve, weights as W
+    from bridgelang_amd.extern.hf.configuration_prismatic import OpenVLAConfig
+    from bridgelang_amd.extern.hf.modeling_prismatic import OpenVLAForActionPrediction
+    from bridgelang_amd.extern.hf.processing_prismatic import PrismaticProcessor
+    stats = {"bridge_orig": {"action": {"q01": [-0.5] * 7, "q99": [0.7] * 7, "mask": [True] * 6 + [False]}}}
+    vla = OpenVLAForActionPrediction(OpenVLAConfig(norm_stats=stats), device=dev, dims=W.tiny_dims()).init_synthetic(seed=11)
+    proc = PrismaticProcessor(tokenizer=CharTokenizer())
+    instr = "stack the blocks"
+    rng = np.random.default_rng(3)
+    imgs = [rng.integers(0, 256, (224, 224, 3), dtype=np.uint8) for _ in range(23)]
+
+    def direct(img):
+        x = proc(serve.get_openvla_prompt(instr, "openvla/openvla-7b"), Image.fromarray(img).convert("RGB"))
+        return vla.predict_action(input_ids=x["input_ids"].to(dev), pixel_values=x["pixel_values"].to(dev, torch.bfloat16),
+                                  unnorm_key="bridge_orig", do_sample=False)
+
+    want = [direct(i) for i in imgs]
+    server = serve.OpenVLAServer(vla, proc, pipeline_batch=2, max_wait_ms=20)
+    out = [None] * len(imgs)
+
+    def worker(i):
+        out[i] = serve.decode_tree(server.predict_action({"image": serve.encode_ndarray(imgs[i]), "instruction": instr,
+                                                          "unnorm_key": "bridge_orig"}))
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(len(imgs))]
+    [t.start() for t in ts]
+    [t.join(timeout=120) for t in ts]
+    assert all(isinstance(o, np.ndarray) and o.shape == (7,) and np.isfinite(o).all() for o in out), out
+    same = sum(bool(np.array_equal(o, w)) for o, w in zip(out, want))
+    print(f"\nthroughput-mode server: {same}/{len(imgs)} answers identical to the plain engine; GPU batches {server.batch_sizes}")
+    assert same >= int(0.6 * len(imgs))
+    assert sum(server.batch_sizes) == len(imgs) and len(server.batch_sizes) >= 12
+    # a lone request afterwards: one tick + drain
+    lone = serve.decode_tree(server.predict_action({"image": serve.encode_ndarray(imgs[0]), "instruction": instr}))
+    assert lone.shape == (7,)
+    # a bad unnorm_key fails that request only
+    assert server.predict_action({"image": serve.encode_ndarray(imgs[1]), "instruction": instr, "unnorm_key": "nope"}) == "error"
+    ok = serve.decode_tree(server.predict_action({"image": serve.encode_ndarray(imgs[1]), "instruction": instr}))
+    assert ok.shape == (7,)
+    server.close()
