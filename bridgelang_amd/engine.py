@@ -135,70 +135,80 @@ class OpenVLAEngine:
                 self._g(self.p1, w.fc2_w, self.p2, EPI_BIAS_GELU, bias=w.fc2_b, run=False),
                 self._g(self.p2, w.fc3_w, self.x.view(B * S, D), EPI_BIAS, bias=w.fc3_b, out_map=(256, S, 1), run=False)]
 
-    def _plan_prefill(self) -> List[Op]:
-        d, w, B, S = self.dims, self.w, self.B, self.S
+    def _plan_prefill(self, b0: int = 0, b1: Optional[int] = None) -> List[Op]:
+        """Llama prefill + first token for batch rows [b0, b1) (default: the whole batch). Every buffer is batch-major, so
+        a batch range is a contiguous slice of each; results do not depend on the range a sequence is run in."""
+        d, w, S = self.dims, self.w, self.S
+        b1 = self.B if b1 is None else b1
+        B = b1 - b0
         D, H, hd = d.llm_dim, d.llm_heads, d.head_dim
-        x = self.x.view(B * S, D)
-        plan = [ops.embed_splice(self.input_ids, w.embed, self.x, d.n_patches, run=False)]
+        rows = slice(b0 * S, b1 * S)
+        x3 = self.x[b0:b1]
+        x = x3.view(B * S, D)
+        h, qkv, ao, act = self.h[rows], self.qkv[rows], self.ao[rows], self.act[rows]
+        xd, hdd, aod, actd = self.xd[b0:b1], self.hd[b0:b1], self.aod[b0:b1], self.actd[b0:b1]
+        key_mask = self.key_mask[b0:b1] if self.key_mask is not None else None
+        plan = [ops.embed_splice(self.input_ids[b0:b1], w.embed, x3, d.n_patches, run=False)]
         cs = (H * self.cache_len * hd, self.cache_len * hd, hd)
         # Generation consumes only the last position of the last layer (the reference materialises all S rows of every
         # layer, SURVEY App. C.5): that layer still projects K/V for every position (the decode steps attend to them),
         # but its attention, o_proj, MLP run on the B last rows only — single-query attention + weight-streaming GEMMs.
         last_rows_only = not self.all_rows and d.llm_layers > 1
         for l, lw in enumerate(w.layers):
-            plan.append(ops.rmsnorm(x, lw.ln1, self.h, d.rms_eps, run=False))
-            plan.append(self._g(self.h, lw.qkv_w, self.qkv, EPI_NONE, run=False))
+            kc, vc = self.k_cache[l][b0:b1], self.v_cache[l][b0:b1]
+            plan.append(ops.rmsnorm(x, lw.ln1, h, d.rms_eps, run=False))
+            plan.append(self._g(h, lw.qkv_w, qkv, EPI_NONE, run=False))
             last = last_rows_only and l == d.llm_layers - 1
             if not last and hd == 128 and S <= 320:
                 # RoPE and the KV-cache write ride inside the attention kernel's q / k / v loads
-                plan.append(ops.attention_rope(self.qkv, self.k_cache[l], self.v_cache[l], self.ao, self.cos, self.sin, B=B,
-                                               S=S, H=H, head_dim=hd, pos0=0, key_mask=self.key_mask, run=False))
-                plan.append(self._g(self.ao, lw.o_w, x, EPI_RES, res=x, run=False))
-                plan.append(ops.rmsnorm(x, lw.ln2, self.h, d.rms_eps, run=False))
-                plan.append(self._g(self.h, lw.gu_w, self.act, EPI_SWIGLU, run=False))
-                plan.append(self._g(self.act, lw.down_w, x, EPI_RES, res=x, run=False))
+                plan.append(ops.attention_rope(qkv, kc, vc, ao, self.cos, self.sin, B=B, S=S, H=H, head_dim=hd, pos0=0,
+                                               key_mask=key_mask, run=False))
+                plan.append(self._g(ao, lw.o_w, x, EPI_RES, res=x, run=False))
+                plan.append(ops.rmsnorm(x, lw.ln2, h, d.rms_eps, run=False))
+                plan.append(self._g(h, lw.gu_w, act, EPI_SWIGLU, run=False))
+                plan.append(self._g(act, lw.down_w, x, EPI_RES, res=x, run=False))
                 continue
-            plan.append(ops.rope_kvcache(self.qkv, self.cos, self.sin, self.k_cache[l], self.v_cache[l], B=B, S=S, H=H,
-                                         head_dim=hd, pos0=0, run=False))
+            plan.append(ops.rope_kvcache(qkv, self.cos, self.sin, kc, vc, B=B, S=S, H=H, head_dim=hd, pos0=0, run=False))
             if last:
-                q_last = self.qkv.view(B, S, 3 * D)[:, S - 1]                  # roped in place; row stride S·3D
-                x_last = self.x[:, S - 1, :]
-                plan.append(ops.attention_decode(q_last, self.k_cache[l], self.v_cache[l], self.aod, B=B, H=H, Skv=S,
-                                                 head_dim=hd, q_strides=(S * 3 * D, hd, 3 * D), k_strides=cs, v_strides=cs,
+                q_last = qkv.view(B, S, 3 * D)[:, S - 1]                       # roped in place; row stride S·3D
+                x_last = x3[:, S - 1, :]
+                plan.append(ops.attention_decode(q_last, kc, vc, aod, B=B, H=H, Skv=S, head_dim=hd,
+                                                 q_strides=(S * 3 * D, hd, 3 * D), k_strides=cs, v_strides=cs,
                                                  o_strides=(D, hd, D), run=False))
-                plan.append(self._g(self.aod, lw.o_w, self.xd, EPI_RES, res=x_last, run=False))
+                plan.append(self._g(aod, lw.o_w, xd, EPI_RES, res=x_last, run=False))
                 if ops.skinny_supported(B, D, EPI_SWIGLU):
-                    plan.append(self._g(self.xd, lw.gu_w, self.actd, EPI_SWIGLU, a_norm=(lw.ln2, d.rms_eps), run=False))
+                    plan.append(self._g(xd, lw.gu_w, actd, EPI_SWIGLU, a_norm=(lw.ln2, d.rms_eps), run=False))
                 else:
-                    plan.append(ops.rmsnorm(self.xd, lw.ln2, self.hd, d.rms_eps, run=False))
-                    plan.append(self._g(self.hd, lw.gu_w, self.actd, EPI_SWIGLU, run=False))
-                plan.append(self._g(self.actd, lw.down_w, self.xd, EPI_RES, res=self.xd, run=False))
-                return plan + self._head(self.xd, 0)
-            plan.append(ops.attention(self.qkv, self.k_cache[l], self.v_cache[l], self.ao, B=B, H=H, Sq=S, Skv=S,
-                                      head_dim=hd, q_strides=(S * 3 * D, hd, 3 * D), k_strides=cs, v_strides=cs,
-                                      o_strides=(S * D, hd, D), causal=True, key_mask=self.key_mask, run=False))
-            plan.append(self._g(self.ao, lw.o_w, x, EPI_RES, res=x, run=False))
-            plan.append(ops.rmsnorm(x, lw.ln2, self.h, d.rms_eps, run=False))
-            plan.append(self._g(self.h, lw.gu_w, self.act, EPI_SWIGLU, run=False))
-            plan.append(self._g(self.act, lw.down_w, x, EPI_RES, res=x, run=False))
+                    plan.append(ops.rmsnorm(xd, lw.ln2, hdd, d.rms_eps, run=False))
+                    plan.append(self._g(hdd, lw.gu_w, actd, EPI_SWIGLU, run=False))
+                plan.append(self._g(actd, lw.down_w, xd, EPI_RES, res=xd, run=False))
+                return plan + self._head(xd, 0, b0, b1)
+            plan.append(ops.attention(qkv, kc, vc, ao, B=B, H=H, Sq=S, Skv=S, head_dim=hd,
+                                      q_strides=(S * 3 * D, hd, 3 * D), k_strides=cs, v_strides=cs,
+                                      o_strides=(S * D, hd, D), causal=True, key_mask=key_mask, run=False))
+            plan.append(self._g(ao, lw.o_w, x, EPI_RES, res=x, run=False))
+            plan.append(ops.rmsnorm(x, lw.ln2, h, d.rms_eps, run=False))
+            plan.append(self._g(h, lw.gu_w, act, EPI_SWIGLU, run=False))
+            plan.append(self._g(act, lw.down_w, x, EPI_RES, res=x, run=False))
         if self.all_rows:   # HF semantics: logits for every position (what forward()/training consume)
-            plan.append(ops.rmsnorm(x, w.norm, self.h, d.rms_eps, run=False))
-            plan.append(self._g(self.h, w.lm_head, self.logits_all, EPI_F32_BF16R, run=False))
+            plan.append(ops.rmsnorm(x, w.norm, h, d.rms_eps, run=False))
+            plan.append(self._g(h, w.lm_head, self.logits_all[rows], EPI_F32_BF16R, run=False))
             return plan
         # final norm + lm_head on the last position only (the reference materialises all S rows, SURVEY App. C.5)
-        last = self.x[:, S - 1, :]
-        plan += self._head(last, 0)
+        plan += self._head(x3[:, S - 1, :], 0, b0, b1)
         return plan
 
-    def _head(self, x_rows: torch.Tensor, t: int) -> List[Op]:
+    def _head(self, x_rows: torch.Tensor, t: int, b0: int = 0, b1: Optional[int] = None) -> List[Op]:
         """final RMSNorm → lm_head (bf16-rounded fp32 logits) → greedy argmax, for generation step t."""
         d, w = self.dims, self.w
-        if ops.skinny_supported(self.B, d.llm_dim, EPI_F32_BF16R):   # RMSNorm fused into the weight-streaming GEMM
-            plan = [self._g(x_rows, w.lm_head, self.logits[t], EPI_F32_BF16R, a_norm=(w.norm, d.rms_eps), run=False)]
+        b1 = self.B if b1 is None else b1
+        logits, ids, hdd = self.logits[t][b0:b1], self.gen_ids[t][b0:b1], self.hd[b0:b1]
+        if ops.skinny_supported(b1 - b0, d.llm_dim, EPI_F32_BF16R):   # RMSNorm fused into the weight-streaming GEMM
+            plan = [self._g(x_rows, w.lm_head, logits, EPI_F32_BF16R, a_norm=(w.norm, d.rms_eps), run=False)]
         else:
-            plan = [ops.rmsnorm(x_rows, w.norm, self.hd, d.rms_eps, run=False),
-                    self._g(self.hd, w.lm_head, self.logits[t], EPI_F32_BF16R, run=False)]
-        plan.append(ops.argmax(self.logits[t], self.gen_ids[t], run=False))
+            plan = [ops.rmsnorm(x_rows, w.norm, hdd, d.rms_eps, run=False),
+                    self._g(hdd, w.lm_head, logits, EPI_F32_BF16R, run=False)]
+        plan.append(ops.argmax(logits, ids, run=False))
         return plan
 
     def _plan_decode(self, t: int) -> List[Op]:
