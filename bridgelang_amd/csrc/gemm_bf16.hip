@@ -861,7 +861,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     // every weight byte once: one workgroup per column slab, all rows; 64-column slabs when that already gives ≥ 160
     // workgroups, else 16-column slabs. grid.y slices K only with a workspace (opt-in).
     const int slabs64 = (p.N + 63) / 64, nkm = p.K / BK;
-    bool wide = slabs64 >= 160;
+    bool wide = slabs64 >= 160;   // measured: 64-column slabs for N = 4096 without K slicing (64 workgroups) cost +2.2 ms at B = 1
     int S = 1;
     static const bool no_split_mid = getenv("BL_GEMM_NO_SPLITK") != nullptr;
     if (!wide && p.slab && !no_split_mid && slabs64 * 2 <= CUS) {
