@@ -63,6 +63,8 @@ SIGNATURES = {
     "bl_fill_synth_bf16": (C.c_int, [_vp, _i64, _u32, _f32, _f32, _vp]),
     "bl_fill_synth_bf16_2d": (C.c_int, [_vp, _i64, _i64, _i64, _u32, _f32, _f32, _vp]),
     "bl_pack_weight_bf16": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "bl_gemm_fp8": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp]),
+    "bl_quantize_rows_fp8": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
     "bl_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "bl_gemm_skinny_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "bl_layernorm_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),

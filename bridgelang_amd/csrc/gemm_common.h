@@ -16,6 +16,7 @@ struct GemmArgs {
   const uint16_t* norm_w; float norm_eps;   // fused RMSNorm on A (skinny kernel)
   float* slab; long slab_bytes; int splitk;   // split-K tail of the 256x256 kernel (fp32 partial tiles)
   int tail_base;   // >= 0: this launch covers big (256x256) tiles tail_base.. of the tiles_m x tiles_n big-tile grid
+  const float* qa; const float* qw;   // fp8 GEMM: per-row activation / per-column weight dequantisation scales
 };
 
 __device__ __forceinline__ int out_row_of(const GemmArgs& p, int m) {
@@ -92,6 +93,7 @@ inline int fill_gemm_args(const bl_gemm_desc* d, GemmArgs& a) {
   a.tail_base = -1;
   a.slab = (float*)d->workspace; a.slab_bytes = d->workspace_bytes; a.splitk = 1;
   a.norm_w = d->a_norm_weight; a.norm_eps = d->a_norm_eps;
+  a.qa = a.qw = nullptr;
   return BL_OK;
 }
 

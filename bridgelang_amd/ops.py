@@ -19,7 +19,7 @@ from . import _lib
 from ._lib import (AttnDesc, GemmDesc, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_F32, EPI_F32_BF16R, EPI_NONE,
                    EPI_RES, EPI_SWIGLU)
 
-__all__ = ["Op", "gemm", "pack_weight", "unpack_weight", "cross_entropy", "layernorm", "rmsnorm", "attention", "attention_rope", "attention_decode", "attention_decode_rope", "attention_decode_rope_grouped", "skinny_supported", "rope_kvcache", "embed_splice",
+__all__ = ["Op", "gemm", "gemm_fp8", "quantize_rows_fp8", "quantize_weight_fp8", "pack_weight", "unpack_weight", "cross_entropy", "layernorm", "rmsnorm", "attention", "attention_rope", "attention_decode", "attention_decode_rope", "attention_decode_rope_grouped", "skinny_supported", "rope_kvcache", "embed_splice",
            "argmax", "im2col_patch14", "preprocess_u8", "resample_coeffs", "resize_bicubic_u8", "write_prefix_tokens", "fill_synth", "run_all",
            "EPI_NONE", "EPI_BIAS", "EPI_BIAS_GELU", "EPI_BIAS_RES", "EPI_RES", "EPI_SWIGLU", "EPI_F32", "EPI_F32_BF16R"]
 
@@ -154,6 +154,82 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, epilogue: int = EP
     op = Op("bl_gemm_skinny_bf16" if use_skinny else "bl_gemm_bf16", fn, (C.byref(d),), (d, *keep),
             flops=2.0 * M * (algo_nk[0] if algo_nk else N) * (algo_nk[1] if algo_nk else K),
             nbytes=2.0 * (M * K + N * K) + esz * M * n_out)
+    if run:
+        op.run()
+    return op
+
+
+# ---- FP8 (e4m3) GEMM family — BASELINE configs[4]; no reference counterpart -----------------------------------------
+FP8_MAX = 448.0
+
+
+def quantize_weight_fp8(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """nn.Linear weight [N, K] (bf16, N % 16 == 0, K % 128 == 0) → (packed e4m3 weight, fp32 scale [N]): per output
+    channel scale = amax / 448, RNE cast, then the fragment-major packing of pack_weight on the bytes viewed as bf16
+    pairs (bl_gemm_fp8 reads the same byte layout as bl_gemm_bf16). Load-time work, torch ops."""
+    N, K = w.shape
+    if N % 16 or K % 128:
+        raise ValueError("quantize_weight_fp8: N % 16 == 0 and K % 128 == 0")
+    wf = w.float()
+    amax = wf.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / FP8_MAX, torch.ones_like(amax))
+    q = (wf / scale[:, None]).to(torch.float8_e4m3fn)
+    packed = pack_weight(q.view(torch.uint8).view(N, K // 2, 2).view(torch.bfloat16).reshape(N, K // 2).contiguous())
+    return packed, scale.contiguous()
+
+
+def quantize_rows_fp8(x: torch.Tensor, q: Optional[torch.Tensor] = None, scales: Optional[torch.Tensor] = None,
+                      run: bool = True):
+    """Activations bf16 [rows, cols] → (e4m3 codes uint8 [rows, cols], fp32 scale per row = amax / 448)
+    (bl_quantize_rows_fp8). Returns (q, scales, op)."""
+    lib = _lib.load()
+    _bf16(x, "x")
+    rows, cols = x.shape
+    if q is None:
+        q = torch.empty(rows, cols, dtype=torch.uint8, device=x.device)
+    if scales is None:
+        scales = torch.empty(rows, dtype=torch.float32, device=x.device)
+    op = Op("bl_quantize_rows_fp8", lib.bl_quantize_rows_fp8,
+            (x.data_ptr(), _rows(x, "x"), rows, cols, q.data_ptr(), q.stride(0), scales.data_ptr()), (x, q, scales),
+            nbytes=3.0 * rows * cols)
+    if run:
+        op.run()
+    return q, scales, op
+
+
+def gemm_fp8(A8: torch.Tensor, scale_a: torch.Tensor, W8: torch.Tensor, scale_w: torch.Tensor, out: torch.Tensor,
+             epilogue: int = EPI_NONE, *, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+             run: bool = True) -> Op:
+    """out = epilogue(scale_a[m] · scale_w[n] · (A8 @ W8.T)) on the fp8 MFMA path (bl_gemm_fp8). A8 uint8 e4m3 codes
+    [M, K]; W8 = quantize_weight_fp8(...)[0]."""
+    lib = _lib.load()
+    if A8.dtype != torch.uint8 or not A8.is_cuda or A8.stride(1) != 1:
+        raise TypeError("gemm_fp8: A8 must be a CUDA/HIP uint8 matrix of e4m3 codes")
+    if W8.dim() != 4 or W8.shape[2:] != (64, 8) or not W8.is_contiguous():
+        raise ValueError("gemm_fp8: W8 must come from quantize_weight_fp8")
+    M, K = A8.shape
+    N, Kw = W8.shape[0] * 16, W8.shape[1] * 64
+    if Kw != K:
+        raise ValueError(f"gemm_fp8: K mismatch A{tuple(A8.shape)} W K={Kw}")
+    want = torch.float32 if epilogue in (EPI_F32, EPI_F32_BF16R) else torch.bfloat16
+    if out.dtype != want or scale_a.dtype != torch.float32 or scale_w.dtype != torch.float32:
+        raise TypeError("gemm_fp8: out dtype / fp32 scales")
+    if scale_a.numel() < M or scale_w.numel() != N:
+        raise ValueError("gemm_fp8: scale_a [M], scale_w [N]")
+    d = GemmDesc()
+    d.A, d.lda = A8.data_ptr(), A8.stride(0)
+    d.W, d.ldw = W8.data_ptr(), K
+    d.C, d.ldc = out.data_ptr(), _rows(out, "out")
+    d.M, d.N, d.K, d.epilogue = M, N, K, epilogue
+    keep = [A8, W8, out, scale_a, scale_w]
+    if bias is not None:
+        d.bias = _bf16(bias, "bias").data_ptr(); keep.append(bias)
+    if res is not None:
+        d.res, d.ldres = _bf16(res, "res").data_ptr(), _rows(res, "res"); keep.append(res)
+    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    esz = 4 if epilogue in (EPI_F32, EPI_F32_BF16R) else 2
+    op = Op("bl_gemm_fp8", lib.bl_gemm_fp8, (C.byref(d), scale_a.data_ptr(), scale_w.data_ptr()), (d, *keep),
+            flops=2.0 * M * N * K, nbytes=1.0 * (M * K + N * K) + esz * M * n_out)
     if run:
         op.run()
     return op

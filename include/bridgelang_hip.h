@@ -102,6 +102,18 @@ int bl_gemm_bf16(const bl_gemm_desc* d, void* stream);
  * cached-decode branch (modeling_prismatic.py:325-341). */
 int bl_gemm_skinny_bf16(const bl_gemm_desc* d, void* stream);
 
+/* ---- FP8 (OCP e4m3) GEMM family — BASELINE configs[4] "fp8 MFMA GEMMs"; the reference has no fp8 path ------------- */
+/* C = epilogue(scale_a[m] * scale_w[n] * (A8 @ W8^T)) on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales, 2x the
+ * bf16 MFMA rate). d->A: e4m3 codes [M, K] (lda in bytes, % 16), d->W: e4m3 weight in the fragment-major packing of
+ * bl_pack_weight_bf16 applied to the [N, K/2] matrix of byte pairs, K % 128 == 0; scale_a fp32 [M] (per token),
+ * scale_w fp32 [N] (per output channel, 16-byte aligned). Epilogues, bias / residual / output as bl_gemm_bf16; no
+ * workspace, no fused A-norm. */
+int bl_gemm_fp8(const bl_gemm_desc* d, const float* scale_a, const float* scale_w, void* stream);
+/* x bf16 [rows, cols] (cols % 8 == 0) -> q e4m3 [rows, cols] (ldq bytes) + scales[row] = amax(row) / 448 (1 for a zero row);
+ * q = RNE_e4m3(x * (448 / amax)). */
+int bl_quantize_rows_fp8(const bl_bf16* x, int64_t ldx, int32_t rows, int32_t cols, uint8_t* q, int64_t ldq, float* scales,
+                         void* stream);
+
 /* ---- normalisation ------------------------------------------------------------------------------------------ */
 /* timm Block.norm1/norm2: LayerNorm(eps, affine), fp32 statistics, bf16 out. y may alias x. */
 int bl_layernorm_bf16(const bl_bf16* x, int64_t ldx, const bl_bf16* w, const bl_bf16* b, bl_bf16* y, int64_t ldy,
