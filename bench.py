@@ -29,6 +29,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 (guides/MI355X_MICROARCH.md)
+FP8_MFMA_PEAK_TFLOPS = 5000.0      # dense fp8 through the block-scaled MFMA (same table)
 HBM_PEAK_GBS = 8000.0
 ALGO_TFLOP_PER_SEQ = 4.238         # SURVEY §8d / BASELINE.md §2, openvla-7b, S = 288, KV cache, last-row lm_head
 
@@ -43,6 +44,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--model", default="openvla-7b", choices=["openvla-7b", "openvla-tiny", "prism-13b"])
     ap.add_argument("--no-graph", action="store_true", help="replay the op plan eagerly instead of as one HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp8", action="store_true", help="Llama prefill projections as W8A8 e4m3 GEMMs (BASELINE configs[4] extension; not the bf16 headline)")
     ap.add_argument("--pipeline", type=int, default=7, choices=[1, 2, 7, 8],
                     help="2 = overlap batch i's decode with batch i+1's vision+prefill (TwoStagePipeline); 7 = StaggeredDecodePipeline "
                          "(one merged decode iteration over the 6 older batches per step)")
@@ -186,7 +188,7 @@ def main() -> None:
         return replicas.max_over_ranks(time.perf_counter() - t0, dev)
 
     # ---- one batch in flight (the latency-oriented predict_action path) ----
-    eng = OpenVLAEngine(w, args.batch, args.prompt_len)
+    eng = OpenVLAEngine(w, args.batch, args.prompt_len, fp8=args.fp8)
     eng.set_inputs(ids, pv)                      # inputs resident in HBM before the timed region
     if args.no_graph:
         eng.run_eager()
@@ -209,7 +211,7 @@ def main() -> None:
         elapsed = timed(pipe.step, args.steps)   # every step completes one batch (submitted one step earlier)
     elif args.pipeline >= 7:
         from bridgelang_amd.pipeline import StaggeredDecodePipeline
-        pipe = StaggeredDecodePipeline(w, args.batch, args.prompt_len, split_vision=args.pipeline == 8)
+        pipe = StaggeredDecodePipeline(w, args.batch, args.prompt_len, split_vision=args.pipeline == 8, fp8=args.fp8)
         for e in pipe.engines:
             e.set_inputs(ids, pv)
         if not args.no_graph:
@@ -226,21 +228,22 @@ def main() -> None:
         seqs = world * args.batch * args.steps
         value = seqs / elapsed
         prof = per_kernel_profile(eng)
-        gemm = prof["bl_gemm_bf16"]
+        gemm = prof["bl_gemm_fp8" if args.fp8 else "bl_gemm_bf16"]     # the dominant kernel of the mode measured
+        peak = FP8_MFMA_PEAK_TFLOPS if args.fp8 else BF16_MFMA_PEAK_TFLOPS
         achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
         skinny = prof.get("bl_gemm_skinny_bf16")
         kern_ms = sum(a["ms"] for a in prof.values())
         traffic = None      # HBM bytes per GEMM call from the committed PMC passes (bench.py cannot run rocprofv3 itself)
         pmc = ROOT / "profiles" / "pmc_r01" / "gemm_traffic.json"
-        if pmc.exists() and args.model == "openvla-7b" and args.batch == 16 and args.prompt_len == 32:
+        if pmc.exists() and args.model == "openvla-7b" and args.batch == 16 and args.prompt_len == 32 and not args.fp8:
             traffic = round(json.loads(pmc.read_text())["avg_hbm_bytes_per_call_llama_layer"])
         # algorithmic work per sequence: the SURVEY figure for the BASELINE model, the plan's own GEMM + attention FLOPs otherwise
         algo = ALGO_TFLOP_PER_SEQ if args.model == "openvla-7b" else sum(op.flops for op in eng.all_ops()) / args.batch / 1e12
         line = {
-            "metric": f"action-seqs/sec (7-DoF, 224px) {dims.name} bf16", "value": round(value, 3), "unit": "action-seqs/s",
+            "metric": f"action-seqs/sec (7-DoF, 224px) {dims.name} {'fp8' if args.fp8 else 'bf16'}", "value": round(value, 3), "unit": "action-seqs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "fp8-e4m3 (W8A8 Llama prefill projections) + bf16" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": (f"{dims.name} bf16 inference (BASELINE configs[1]): batch {args.batch} synthetic 224px "
                                     f"frames + {args.prompt_len}-token prompts per GPU, predict_action = vision towers + "
                                     f"projector + Llama prefill S={eng.S} + 6 cached decode steps, greedy"
@@ -251,10 +254,11 @@ def main() -> None:
                                           "pass over the weights; one batch completes per step"}.get(args.pipeline, "8 in flight")),
                        "batch_per_gpu": args.batch, "prompt_len": args.prompt_len, "seq_len": eng.S,
                        "replicas": world, "hip_graph": not args.no_graph, "pipeline_depth": args.pipeline},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_note": "avg HBM+Infinity-Cache bytes per bl_gemm_bf16 call over the 4 Llama prefill GEMMs, separate --pmc passes (profiles/pmc_r01/gemm_traffic.json)",
-                         "kernel": "gemm256s_kernel + gemm_tail_kernel / gemm128_kernel (per bl_gemm_bf16 call)", "launches_per_step": gemm["launches"],
+                         "kernel": ("gemm256s_fp8_kernel (per bl_gemm_fp8 call)" if args.fp8 else
+                                    "gemm256s_kernel + gemm_tail_kernel / gemm128_kernel (per bl_gemm_bf16 call)"), "launches_per_step": gemm["launches"],
                          "avg_launch_us": round(gemm["ms"] * 1e3 / gemm["launches"], 2),
                          "algorithmic_gflop_per_launch": round(gemm["flops"] / gemm["launches"] / 1e9, 3)},
             "end_to_end": {"algorithmic_tflop_per_seq": round(algo, 3),

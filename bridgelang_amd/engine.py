@@ -27,15 +27,31 @@ def rope_tables(head_dim: int, max_pos: int, theta: float, device) -> tuple:
     return fr.cos().to(torch.bfloat16).to(device), fr.sin().to(torch.bfloat16).to(device)
 
 
+_FP8_CACHE: dict = {}
+
+
+def _fp8_layers(weights: VLAWeights) -> list:
+    """e4m3 copies (+ per-channel scales) of the Llama projection weights, quantised once per weight set from the packed
+    bf16 arena (ops.quantize_weight_fp8); shared by every engine built over these weights."""
+    key = id(weights)
+    if key not in _FP8_CACHE:
+        _FP8_CACHE[key] = [{n: ops.quantize_weight_fp8(ops.unpack_weight(getattr(lw, n))) for n in ("qkv_w", "o_w", "gu_w", "down_w")}
+                           for lw in weights.layers]
+    return _FP8_CACHE[key]
+
+
 class OpenVLAEngine:
     def __init__(self, weights: VLAWeights, batch: int, prompt_len: int, n_new: int = 7, all_rows: bool = False,
-                 use_mask: bool = False, splitk: bool = False):
+                 use_mask: bool = False, splitk: bool = False, fp8: bool = False):
         """all_rows=True builds the training/eval-style forward instead of generation: logits for every position
         (`logits_all` [B*S, vocab] fp32) and no decode steps. use_mask=True threads a [B, S] uint8 key-padding mask
         (`key_mask`, 1 = attend) through the Llama attention (modeling_prismatic.py:387-390). splitk=True lets
         bl_gemm_bf16 split the K range of the last, partially filled round of tiles (≈ +2 % throughput at 7B) — OFF by
         default because those rows then sum in a different fp32 order than the rest, so a sequence's result would depend
-        on its batch slot (it breaks "batch-B ≡ B × batch-1 bit for bit", tests/test_full_size_gpu.py)."""
+        on its batch slot (it breaks "batch-B ≡ B × batch-1 bit for bit", tests/test_full_size_gpu.py). fp8=True runs the
+        Llama prefill projections (qkv, o, gate/up, down of every layer but the last) as W8A8 e4m3 GEMMs on the
+        block-scaled MFMA (BASELINE configs[4]; per-token × per-channel scales, ops.gemm_fp8) — an extension with no
+        reference counterpart: results agree with the bf16 path to quantisation noise, not bit for bit."""
         self.w, self.dims = weights, weights.dims
         d = self.dims
         if all_rows:
@@ -78,6 +94,13 @@ class OpenVLAEngine:
         self.ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev) if splitk else None   # split-K scratch (opt-in)
         self.key_mask = torch.ones(B, S, dtype=torch.uint8, device=dev) if use_mask else None
         self.logits_all = z(B * S, d.vocab, dtype=torch.float32) if all_rows else None
+        self.fp8 = fp8
+        if fp8:
+            if d.llm_dim % 128 or d.llm_inter % 128:
+                raise ValueError("fp8 prefill needs llm_dim and llm_inter to be multiples of 128")
+            self.w8 = _fp8_layers(weights)
+            self.h8, self.act8 = z(B * S, D, dtype=torch.uint8), z(B * S, I, dtype=torch.uint8)
+            self.sq = z(B * S, dtype=torch.float32)
 
         self.dino_ops = self._plan_tower(weights.dino, 0, self.vbuf[0])
         self.siglip_ops = self._plan_tower(weights.siglip, d.dino.dim, self.vbuf[1])
@@ -159,6 +182,21 @@ class OpenVLAEngine:
             plan.append(ops.rmsnorm(x, lw.ln1, h, d.rms_eps, run=False))
             plan.append(self._g(h, lw.qkv_w, qkv, EPI_NONE, run=False))
             last = last_rows_only and l == d.llm_layers - 1
+            if self.fp8 and not last and hd == 128 and S <= 320:
+                w8, h8, act8, sq = self.w8[l], self.h8[rows], self.act8[rows], self.sq[rows]
+                q8 = lambda src, dst: ops.quantize_rows_fp8(src, dst, sq, run=False)[2]
+                plan[-1] = q8(h, h8)                                           # replaces the bf16 qkv GEMM appended above
+                plan.append(ops.gemm_fp8(h8, sq, *w8["qkv_w"], qkv, EPI_NONE, run=False))
+                plan.append(ops.attention_rope(qkv, kc, vc, ao, self.cos, self.sin, B=B, S=S, H=H, head_dim=hd, pos0=0,
+                                               key_mask=key_mask, run=False))
+                plan.append(q8(ao, h8))
+                plan.append(ops.gemm_fp8(h8, sq, *w8["o_w"], x, EPI_RES, res=x, run=False))
+                plan.append(ops.rmsnorm(x, lw.ln2, h, d.rms_eps, run=False))
+                plan.append(q8(h, h8))
+                plan.append(ops.gemm_fp8(h8, sq, *w8["gu_w"], act, EPI_SWIGLU, run=False))
+                plan.append(q8(act, act8))
+                plan.append(ops.gemm_fp8(act8, sq, *w8["down_w"], x, EPI_RES, res=x, run=False))
+                continue
             if not last and hd == 128 and S <= 320:
                 # RoPE and the KV-cache write ride inside the attention kernel's q / k / v loads
                 plan.append(ops.attention_rope(qkv, kc, vc, ao, self.cos, self.sin, B=B, S=S, H=H, head_dim=hd, pos0=0,

@@ -90,7 +90,8 @@ class StaggeredDecodePipeline:
     weight-streaming kernel): same tokens unless the top-2 logit gap is inside bf16 noise (tests/test_pipeline_gpu.py).
     """
 
-    def __init__(self, weights: VLAWeights, batch: int, prompt_len: int, n_new: int = 7, split_vision: bool = False):
+    def __init__(self, weights: VLAWeights, batch: int, prompt_len: int, n_new: int = 7, split_vision: bool = False,
+                 fp8: bool = False):
         """split_vision=True adds a third stage: the vision towers + projector of the batch submitted NOW run beside the
         Llama prefill of the batch submitted one step earlier (n_new + 1 slots, latency n_new + 1 steps)."""
         if n_new < 2:
@@ -99,7 +100,7 @@ class StaggeredDecodePipeline:
         self.split_vision = split_vision
         self.lag = 1 if split_vision else 0         # steps between a batch's submission and its prefill
         self.slots = n_new + self.lag
-        self.engines = [OpenVLAEngine(weights, batch, prompt_len, n_new) for _ in range(self.slots)]
+        self.engines = [OpenVLAEngine(weights, batch, prompt_len, n_new, fp8=fp8) for _ in range(self.slots)]
         self.device = dev = weights.embed.device
         d = self.dims
         G = n_new - 1

@@ -99,3 +99,27 @@ def test_gemm_fp8_rejects(dev):
     W8, sw = ops.quantize_weight_fp8(torch.ones(64, 256, dtype=torch.bfloat16, device=dev))
     with pytest.raises(ValueError):
         ops.gemm_fp8(A8, torch.ones(64, device=dev), W8, sw, torch.zeros(64, 64, dtype=torch.bfloat16, device=dev))
+
+
+def test_engine_fp8_prefill_close_to_bf16(dev):
+    """fp8=True engine (W8A8 prefill projections) vs the bf16 engine on a reduced-width model with Llama-sized channels
+    (multiples of 128): first-token logits agree to quantisation noise; the stated bound is 8 % of the logit scale."""
+    import dataclasses
+    from bridgelang_amd import weights as W
+    from bridgelang_amd.engine import OpenVLAEngine
+    from test_engine_gpu import make_inputs
+    dims = W.tiny_dims()
+    if dims.llm_dim % 128 or dims.llm_inter % 128 or dims.head_dim != 128:
+        dims = dataclasses.replace(dims, llm_dim=512, llm_heads=4, head_dim=128, llm_inter=1536)
+    w = W.allocate(dims, dev).fill_synthetic(seed=5)
+    B, L = 3, 9
+    ids, pv = make_inputs(dims, B, L, seed=1)
+    e16, e8 = OpenVLAEngine(w, B, L), OpenVLAEngine(w, B, L, fp8=True)
+    a = e16.generate(ids.to(dev), pv.to(dev)).clone()
+    la = e16.logits[0].clone()
+    b = e8.generate(ids.to(dev), pv.to(dev)).clone()
+    lb = e8.logits[0].clone()
+    assert any(op.name == "bl_gemm_fp8" for op in e8.prefill_ops) and not any(op.name == "bl_gemm_fp8" for op in e16.prefill_ops)
+    rel = ((la - lb).abs().amax() / la.abs().amax()).item()
+    print(f"\nfp8 prefill vs bf16: max |dlogit| / scale = {rel:.4f}; first tokens equal: {(a[:, 0] == b[:, 0]).float().mean().item():.2f}")
+    assert 0 < rel <= 0.08
