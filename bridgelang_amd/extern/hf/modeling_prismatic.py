@@ -104,9 +104,9 @@ class PrismaticForConditionalGeneration:
         return self
 
     def engine(self, batch: int, prompt_len: int) -> OpenVLAEngine:
-        key = (batch, prompt_len)
-        if key not in self._engines:
-            self._engines[key] = OpenVLAEngine(self.weights, batch, prompt_len)
+        key = (batch, prompt_len, bool(getattr(self, "fp8", False)))
+        if key not in self._engines:      # `model.fp8 = True`: W8A8 e4m3 Llama prefill projections (extension, engine.py)
+            self._engines[key] = OpenVLAEngine(self.weights, batch, prompt_len, fp8=key[2])
         return self._engines[key]
 
     # ---- forward (multimodal prefill; logits for all positions) ----
