@@ -708,6 +708,9 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
 #endif
 #define WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
   // H(p+6) for phase q of K-tile T:  q=0 → X1(T+1)   q=1 → Y0(T+2)   q=2 → X0(T+2)   q=3 → Y1(T+2)
+// the fragment reads go first, the LDS-DMA issue second: the ≈ 80 cycles each piece takes to issue cover the reads' latency
+// instead of preceding it (+1.5–2.3 % on every shape, same box A/B)
+#define ISSUE_READ(I, R) do { R; __builtin_amdgcn_sched_barrier(0); I; } while (0)
 #define ISSUE_Q0(T) ISSUE_X(1, (T) + 1)
 #define ISSUE_Q1(T) ISSUE_Y(0, (T) + 2)
 #define ISSUE_Q2(T) ISSUE_X(0, (T) + 2)
@@ -752,15 +755,15 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
     BAR();
     for (int t = t0; t < nk; t += 2) {
       // K-tile t (stage 0): Y0 in Ya, Y1 → Yb
-      MMA(X, Ya, 0, 0); WAIT_VM8(); BAR();   ISSUE_Q0(t);     READ_Y(Yb, 1, S0); WAIT_LGKM(); BAR();
-      MMA(X, Yb, 0, 1); WAIT_VM8(); BAR();   ISSUE_Q1(t);     READ_X(X, 1, S0);  WAIT_LGKM(); BAR();
-      MMA(X, Yb, 1, 1); WAIT_VM8(); BAR();   ISSUE_Q2(t);     READ_Y(Yb, 0, S1); WAIT_LGKM(); BAR();
-      MMA(X, Ya, 1, 0); WAIT_VM8(); BAR();   ISSUE_Q3(t);     READ_X(X, 0, S1);  WAIT_LGKM(); BAR();
+      MMA(X, Ya, 0, 0); WAIT_VM8(); BAR();   ISSUE_READ(ISSUE_Q0(t), READ_Y(Yb, 1, S0)); WAIT_LGKM(); BAR();
+      MMA(X, Yb, 0, 1); WAIT_VM8(); BAR();   ISSUE_READ(ISSUE_Q1(t), READ_X(X, 1, S0));  WAIT_LGKM(); BAR();
+      MMA(X, Yb, 1, 1); WAIT_VM8(); BAR();   ISSUE_READ(ISSUE_Q2(t), READ_Y(Yb, 0, S1)); WAIT_LGKM(); BAR();
+      MMA(X, Ya, 1, 0); WAIT_VM8(); BAR();   ISSUE_READ(ISSUE_Q3(t), READ_X(X, 0, S1));  WAIT_LGKM(); BAR();
       // K-tile t+1 (stage 1): Y0 in Yb, Y1 → Ya
-      MMA(X, Yb, 0, 0); WAIT_VM8(); BAR();   ISSUE_Q0(t + 1); READ_Y(Ya, 1, S1); WAIT_LGKM(); BAR();
-      MMA(X, Ya, 0, 1); WAIT_VM8(); BAR();   ISSUE_Q1(t + 1); READ_X(X, 1, S1);  WAIT_LGKM(); BAR();
-      MMA(X, Ya, 1, 1); WAIT_VM8(); BAR();   ISSUE_Q2(t + 1); READ_Y(Ya, 0, S0); WAIT_LGKM(); BAR();
-      MMA(X, Yb, 1, 0); WAIT_VM8(); BAR();   ISSUE_Q3(t + 1); READ_X(X, 0, S0);  WAIT_LGKM(); BAR();
+      MMA(X, Yb, 0, 0); WAIT_VM8(); BAR();   ISSUE_READ(ISSUE_Q0(t + 1), READ_Y(Ya, 1, S1)); WAIT_LGKM(); BAR();
+      MMA(X, Ya, 0, 1); WAIT_VM8(); BAR();   ISSUE_READ(ISSUE_Q1(t + 1), READ_X(X, 1, S1));  WAIT_LGKM(); BAR();
+      MMA(X, Ya, 1, 1); WAIT_VM8(); BAR();   ISSUE_READ(ISSUE_Q2(t + 1), READ_Y(Ya, 0, S0)); WAIT_LGKM(); BAR();
+      MMA(X, Yb, 1, 0); WAIT_VM8(); BAR();   ISSUE_READ(ISSUE_Q3(t + 1), READ_X(X, 0, S0));  WAIT_LGKM(); BAR();
     }
     BL_EPILOGUE();
     return;
@@ -769,14 +772,14 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
   WAIT_LGKM();
   BAR();
   for (int t = t0; t < nk; t += 2) {
-    ISSUE_Q0(t);     READ_X(X, 0, S0);  WAIT_VM10_LGKM(); BAR();   MMA(X, Ya, 0, 0); BAR();
-    ISSUE_Q1(t);     READ_Y(Yb, 1, S0); WAIT_VM10_LGKM(); BAR();   MMA(X, Yb, 0, 1); BAR();
-    ISSUE_Q2(t);     READ_X(X, 1, S0);  WAIT_VM10_LGKM(); BAR();   MMA(X, Yb, 1, 1); BAR();
-    ISSUE_Q3(t);     READ_Y(Yb, 0, S1); WAIT_VM10_LGKM(); BAR();   MMA(X, Ya, 1, 0); BAR();
-    ISSUE_Q0(t + 1); READ_X(X, 0, S1);  WAIT_VM10_LGKM(); BAR();   MMA(X, Yb, 0, 0); BAR();
-    ISSUE_Q1(t + 1); READ_Y(Ya, 1, S1); WAIT_VM10_LGKM(); BAR();   MMA(X, Ya, 0, 1); BAR();
-    ISSUE_Q2(t + 1); READ_X(X, 1, S1);  WAIT_VM10_LGKM(); BAR();   MMA(X, Ya, 1, 1); BAR();
-    ISSUE_Q3(t + 1); READ_Y(Ya, 0, S0); WAIT_VM10_LGKM(); BAR();   MMA(X, Yb, 1, 0); BAR();
+    ISSUE_READ(ISSUE_Q0(t), READ_X(X, 0, S0));  WAIT_VM10_LGKM(); BAR();   MMA(X, Ya, 0, 0); BAR();
+    ISSUE_READ(ISSUE_Q1(t), READ_Y(Yb, 1, S0)); WAIT_VM10_LGKM(); BAR();   MMA(X, Yb, 0, 1); BAR();
+    ISSUE_READ(ISSUE_Q2(t), READ_X(X, 1, S0));  WAIT_VM10_LGKM(); BAR();   MMA(X, Yb, 1, 1); BAR();
+    ISSUE_READ(ISSUE_Q3(t), READ_Y(Yb, 0, S1)); WAIT_VM10_LGKM(); BAR();   MMA(X, Ya, 1, 0); BAR();
+    ISSUE_READ(ISSUE_Q0(t + 1), READ_X(X, 0, S1));  WAIT_VM10_LGKM(); BAR();   MMA(X, Yb, 0, 0); BAR();
+    ISSUE_READ(ISSUE_Q1(t + 1), READ_Y(Ya, 1, S1)); WAIT_VM10_LGKM(); BAR();   MMA(X, Ya, 0, 1); BAR();
+    ISSUE_READ(ISSUE_Q2(t + 1), READ_X(X, 1, S1));  WAIT_VM10_LGKM(); BAR();   MMA(X, Ya, 1, 1); BAR();
+    ISSUE_READ(ISSUE_Q3(t + 1), READ_Y(Ya, 0, S0)); WAIT_VM10_LGKM(); BAR();   MMA(X, Yb, 1, 0); BAR();
   }
   BL_EPILOGUE();
 #undef BL_EPILOGUE
@@ -789,6 +792,7 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
 #undef WAIT_VM8
 #undef WAIT_VM10_LGKM
 #undef WAIT_LGKM
+#undef ISSUE_READ
 #undef ISSUE_Q0
 #undef ISSUE_Q1
 #undef ISSUE_Q2
