@@ -710,7 +710,13 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
   // H(p+6) for phase q of K-tile T:  q=0 → X1(T+1)   q=1 → Y0(T+2)   q=2 → X0(T+2)   q=3 → Y1(T+2)
 // the fragment reads go first, the LDS-DMA issue second: the ≈ 80 cycles each piece takes to issue cover the reads' latency
 // instead of preceding it (+1.5–2.3 % on every shape, same box A/B)
+#if defined(BL_EXP_NO_ISSUE)     /* timing experiments only (results invalid): segment cost without the LDS-DMA issue / the reads */
+#define ISSUE_READ(I, R) do { R; } while (0)
+#elif defined(BL_EXP_NO_READ)
+#define ISSUE_READ(I, R) do { I; } while (0)
+#else
 #define ISSUE_READ(I, R) do { R; __builtin_amdgcn_sched_barrier(0); I; } while (0)
+#endif
 #define ISSUE_Q0(T) ISSUE_X(1, (T) + 1)
 #define ISSUE_Q1(T) ISSUE_Y(0, (T) + 2)
 #define ISSUE_Q2(T) ISSUE_X(0, (T) + 2)
