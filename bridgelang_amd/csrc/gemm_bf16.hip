@@ -651,10 +651,12 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
     voffY[nh][1] = voffY[nh][0] + 1024;
     ldsY[nh] = W_OFF + nt * 2048;
   }
+// past the end of K the descriptor's size is 0 (the load then writes zeros): only that one dword of it varies
+#define BL_RS(PTR, BYTES) __builtin_amdgcn_make_buffer_rsrc((void*)(PTR), 0, (BYTES), 0x00020000)
 #define ISSUE_X(MH, TILE)                                                                   \
   do {                                                                                      \
     const int t__ = (TILE);                                                                 \
-    const __amdgpu_buffer_rsrc_t rs__ = t__ < nk ? rsA : rsA0;                              \
+    const __amdgpu_buffer_rsrc_t rs__ = BL_RS(p.A, t__ < nk ? a_bytes : 0u);                \
     char* b__ = smem + (t__ & 1) * STAGE;                                                   \
     BL_GLDS(rs__, b__ + ldsX[MH][0], voffX[MH][0], t__ * 128);                              \
     BL_GLDS(rs__, b__ + ldsX[MH][1], voffX[MH][1], t__ * 128);                              \
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
 #define ISSUE_Y(NH, TILE)                                                                   \
   do {                                                                                      \
     const int t__ = (TILE);                                                                 \
-    const __amdgpu_buffer_rsrc_t rs__ = t__ < nk ? rsW : rsW0;                              \
+    const __amdgpu_buffer_rsrc_t rs__ = BL_RS(p.W, t__ < nk ? w_bytes : 0u);                \
     char* b__ = smem + (t__ & 1) * STAGE;                                                   \
     BL_GLDS(rs__, b__ + ldsY[NH], voffY[NH][0], t__ * 2048);                                \
     BL_GLDS(rs__, b__ + ldsY[NH] + 1024, voffY[NH][1], t__ * 2048);                         \
@@ -709,7 +711,9 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
 #define WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
   // H(p+6) for phase q of K-tile T:  q=0 → X1(T+1)   q=1 → Y0(T+2)   q=2 → X0(T+2)   q=3 → Y1(T+2)
 // the fragment reads go first, the LDS-DMA issue second: the ≈ 80 cycles each piece takes to issue cover the reads' latency
-// instead of preceding it (+1.5–2.3 % on every shape, same box A/B)
+// instead of preceding it (+1.5–2.3 % on every shape, same box A/B). Tried and rejected: moving one of the two pieces between
+// the two k-steps of the wave's next MFMA segment (to thin out the burst of 8 pieces per segment): −3 %, the piece's issue
+// time then stalls the MFMA stream itself.
 #if defined(BL_EXP_NO_ISSUE)     /* timing experiments only (results invalid): segment cost without the LDS-DMA issue / the reads */
 #define ISSUE_READ(I, R) do { R; } while (0)
 #elif defined(BL_EXP_NO_READ)
