@@ -27,17 +27,16 @@ def rope_tables(head_dim: int, max_pos: int, theta: float, device) -> tuple:
     return fr.cos().to(torch.bfloat16).to(device), fr.sin().to(torch.bfloat16).to(device)
 
 
-_FP8_CACHE: dict = {}
-
-
 def _fp8_layers(weights: VLAWeights) -> list:
     """e4m3 copies (+ per-channel scales) of the Llama projection weights, quantised once per weight set from the packed
-    bf16 arena (ops.quantize_weight_fp8); shared by every engine built over these weights."""
-    key = id(weights)
-    if key not in _FP8_CACHE:
-        _FP8_CACHE[key] = [{n: ops.quantize_weight_fp8(ops.unpack_weight(getattr(lw, n))) for n in ("qkv_w", "o_w", "gu_w", "down_w")}
-                           for lw in weights.layers]
-    return _FP8_CACHE[key]
+    bf16 arena (ops.quantize_weight_fp8) and kept on the weights object: shared by every engine built over these weights.
+    (Quantised from the weights as they are NOW: call `weights.__dict__.pop("_fp8_layers", None)` after loading others.)"""
+    cache = weights.__dict__.get("_fp8_layers")
+    if cache is None:
+        cache = [{n: ops.quantize_weight_fp8(ops.unpack_weight(getattr(lw, n))) for n in ("qkv_w", "o_w", "gu_w", "down_w")}
+                 for lw in weights.layers]
+        weights.__dict__["_fp8_layers"] = cache
+    return cache
 
 
 class OpenVLAEngine:
