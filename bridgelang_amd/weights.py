@@ -305,6 +305,7 @@ class VLAWeights:
         weights (bl_pack_weight_bf16); the CPU oracle builds the identical tensors from the same (name, seed, mean,
         std) with oracle/synth.py."""
         from . import ops
+        self.__dict__.pop("_fp8_layers", None)        # derived e4m3 copies (engine.py) follow the bf16 weights
         specs = self._specs()
 
         def fill(flat, name):
@@ -323,6 +324,7 @@ class VLAWeights:
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> "VLAWeights":
         """Pack an HF-named state dict (bf16/fp32 tensors on any device) into the device layout."""
+        self.__dict__.pop("_fp8_layers", None)        # derived e4m3 copies (engine.py) follow the bf16 weights
         specs = self._specs()
         missing = [n for n in specs if n not in sd]
         if strict and missing:
