@@ -425,6 +425,99 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs p) {
 }
 
 // ======================================================================================================================
+// "mid2" kernel: 160 rows × 32 columns per workgroup, 4 waves as 2 (m) × 2 (n), 3-stage ring — the narrow layers
+// (N = 4096 o / down, ViT proj / fc2) at 128 < M ≤ 320. The mid kernel's 16-column slabs re-stage ALL rows of A per
+// workgroup (42 KB per K-step for 0.66 MFLOP), and the CU's global→LDS path (one 1-KiB piece per ≈ 20 cycles) is what
+// bounds it; half the rows and twice the columns stage 24 KB for 0.66 MFLOP with as many workgroups. Same K order per
+// output as every other kernel (bit-identical results).
+// ======================================================================================================================
+template <int EPI, int NT, int NST = 3>   // NT = 16-column tiles per wave: 32·NT columns per workgroup; NST ring stages
+__global__ __launch_bounds__(256) void gemm_mid2_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 160, BN = 32 * NT, MT = 5, LPS = 5 + NT;   // LPS: LDS-DMA pieces per wave and stage (5 A + NT W)
+  constexpr int A_BYTES = BM * ROW_BYTES, BUF_BYTES = A_BYTES + NT * 4096;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // NST × BUF_BYTES
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kt32 = p.K >> 5;
+
+  const unsigned a_bytes = (unsigned)min((long)p.M * p.lda * 2, 0xffffffffL);
+  const unsigned w_bytes = (unsigned)min((long)p.N * p.K * 2, 0xffffffffL);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
+
+  // activation pieces: 20 × (8 rows × 128 B); wave takes pieces j*4 + wave. weight blocks: (n-tile, k-step) = (wave >> 1, wave & 1)
+  const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
+  unsigned voffA[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) voffA[j] = (unsigned)(((long)(m0 + (j * 4 + wave) * 8 + prow) * p.lda) * 2 + pchunk * 16);
+  unsigned voffW[NT];                            // weight block b = j*4 + wave: n-tile b >> 1, k-step b & 1, LDS slot b
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int blk = j * 4 + wave;
+    voffW[j] = (unsigned)(((long)(n0 / 16 + (blk >> 1)) * kt32 + (blk & 1)) * 1024 + lane * 16);
+  }
+
+#define BL_STAGE(BUF, KT)                                                                                   \
+  do {                                                                                                      \
+    char* base__ = smem + (BUF) * BUF_BYTES;                                                                \
+    _Pragma("unroll") for (int j = 0; j < MT; ++j) BL_GLDS(rsA, base__ + (j * 4 + wave) * 1024, voffA[j], (KT) * 128); \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) BL_GLDS(rsW, base__ + A_BYTES + (j * 4 + wave) * 1024, voffW[j], (KT) * 2048); \
+  } while (0)
+
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int c0 = lg ^ (lane & 7);
+  const int offA = (wm * 80 + l15) * ROW_BYTES;
+  const int offW = A_BYTES + (wn * NT) * 2048 + lane * 16;   // block (wn*NT + i)*2 + ks
+
+  f32x4_t acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  static_assert(NST == 2 || NST == 3, "ring depth");
+  BL_STAGE(0, 0);
+  if (NST == 3 && 1 < nk) BL_STAGE(1, 1);
+  for (int kt = 0; kt < nk; ++kt) {
+    // issue K-tile kt+NST-1 into the ring slot read in the previous iteration (all waves are past its barrier), then wait
+    // for K-tile kt with the newer ones still in flight
+    if (kt + NST - 1 < nk) BL_STAGE((kt + NST - 1) % NST, kt + NST - 1);
+    const int later = min(NST - 1, nk - 1 - kt);
+    if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // every wave's pieces of K-tile kt have landed
+    const char* base = smem + (kt % NST) * BUF_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int cb = (c0 ^ (ks * 4)) << 4;
+      bf16x8_t wf[NT], af[MT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) wf[i] = *(const bf16x8_t*)(base + offW + i * 2048 + ks * 1024);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) af[j] = *(const bf16x8_t*)(base + offA + j * 16 * ROW_BYTES + cb);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // all reads of this slot done before it is re-issued next iteration
+  }
+#undef BL_STAGE
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+      epilogue_store4<EPI>(p, m0 + wm * 80 + j * 16 + l15, n0 + (wn * NT + i) * 16 + lg * 4, acc[i][j]);
+#endif
+}
+
+// ======================================================================================================================
 // 256 × 256 tile, half-tile LDS-DMA ring, 4 phases per K-tile
 // ======================================================================================================================
 template <int EPI>
@@ -850,6 +943,12 @@ int set_lds_attr() {
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 192 * ROW_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tail_kernel<EPI, 64, 64, 4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * ROW_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mid2_kernel<EPI, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            3 * (160 * ROW_BYTES + 4096)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mid2_kernel<EPI, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            3 * (160 * ROW_BYTES + 4 * 4096)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mid2_kernel<EPI, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * (160 * ROW_BYTES + 2 * 4096)) != hipSuccess ||
         !mid_attr<EPI, 2, 4>() || !mid_attr<EPI, 4, 4>() || !mid_attr<EPI, 5, 4>() || !mid_attr<EPI, 2, 1>() ||
         !mid_attr<EPI, 4, 1>() || !mid_attr<EPI, 5, 1>())
       return BL_E_LAUNCH;
@@ -871,7 +970,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   bool big = big_tiles >= 200 && p.K >= 512;
   if (force) big = force[0] == '2';
   static const bool no_mid = getenv("BL_GEMM_NO_MID") != nullptr;      // A/B aid
-  if (p.M <= 320 && p.M > 32 && p.K >= 512 && !force && !no_mid) {
+  // M <= 320: the weight-streaming mid kernels; up to 640 rows (B = 2 prefill) the 160-row mid2 kernel still beats the
+  // tile kernels (38.2 -> 36.4 ms per batch), beyond that it loses (B = 4: 42.7 vs 48.2 ms)
+  static const bool no_mid2 = getenv("BL_GEMM_NO_MID2") != nullptr;      // A/B aid
+  const bool mid2_only = p.M > 320;
+  if (p.M <= 640 && p.M > 32 && p.K >= 512 && !force && !no_mid && !(mid2_only && (no_mid2 || p.slab || (p.N % 32)))) {
     // every weight byte once: one workgroup per column slab, all rows; 64-column slabs when that already gives ≥ 160
     // workgroups, else 16-column slabs. grid.y slices K only with a workspace (opt-in).
     const int slabs64 = (p.N + 63) / 64, nkm = p.K / BK;
@@ -885,6 +988,20 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
       int S2 = min(8, CUS / slabs64);
       while (S2 > 1 && (nkm / S2 < 8 || p.slab_bytes < (long)S2 * p.M * p.N * 4)) --S2;
       if (S2 > 1) { wide = true; S = S2; }
+    }
+    if (S == 1 && p.M > 128 && (p.N % 32) == 0 && !no_mid2) {
+      // 160-row workgroups (gemm_mid2_kernel): narrow layers 32 columns (3-stage ring, 2 workgroups per CU); wide layers
+      // 64 columns on a 2-stage ring so that two workgroups share a CU and one's LDS-DMA issue runs under the other's
+      // MFMAs (qkv 59 -> 44 us, gate/up 112 -> 83 us at M = 288); the widest (lm_head) 128 columns.
+      const int mb = (p.M + 159) / 160;
+      if (!wide)
+        hipLaunchKernelGGL((gemm_mid2_kernel<EPI, 1>), dim3(p.N / 32, mb), dim3(256), 3 * (160 * ROW_BYTES + 4096), s, p);
+      else if (slabs64 >= 400)
+        hipLaunchKernelGGL((gemm_mid2_kernel<EPI, 4>), dim3((p.N + 127) / 128, mb), dim3(256), 3 * (160 * ROW_BYTES + 4 * 4096), s, p);
+      else
+        hipLaunchKernelGGL((gemm_mid2_kernel<EPI, 2, 2>), dim3((p.N + 63) / 64, mb), dim3(256), 2 * (160 * ROW_BYTES + 2 * 4096), s, p);
+      BL_CHECK_LAUNCH();
+      return BL_OK;
     }
     const int slabs = wide ? slabs64 : (p.N + 15) / 16;
     if (S == 1 && !wide && p.slab && !no_split_mid && slabs < CUS) {
