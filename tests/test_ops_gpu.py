@@ -470,11 +470,14 @@ def test_resize_bicubic_frames_bit_exact(dev, H, W):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(288, 12288, 4096, "none"), (288, 4096, 1024, "res"), (261, 1024, 4096, "res"), (256, 4352, 1152, "gelu"),
-                                       (100, 192, 512, "gelu"), (33, 64, 1536, "none"), (320, 3072, 1536, "swiglu"), (288, 256, 1088, "res")])
+                                       (100, 192, 512, "gelu"), (33, 64, 1536, "none"), (320, 3072, 1536, "swiglu"), (288, 256, 1088, "res"),
+                                       (576, 4096, 1024, "res"), (640, 12288, 512, "none"), (522, 1024, 1024, "gelu"), (161, 32064, 512, "none"),
+                                       (600, 22016, 512, "swiglu")])
 def test_gemm_mid_rows(dev, M, N, K, epi):
-    """16 < M <= 320 (batch-1 prefill, one image's tokens): the weight-streaming mid kernel vs the oracle, bit-identical
-    to the tile kernels (same K order) so a row's result does not depend on how many rows ran with it; K-sliced with a
-    workspace stays within rounding."""
+    """16 < M <= 640 (batch-1 / batch-2 prefill, one or two images' tokens): the weight-streaming mid kernels (mid: all
+    rows per column slab; mid2: 160-row workgroups, 32 / 64 / 128 columns) vs the oracle, bit-identical to the tile kernels
+    (same K order) so a row's result does not depend on how many rows ran with it; K-sliced with a workspace stays
+    within rounding."""
     from bridgelang_amd import ops
     Mbig = 700
     a, w, b, r = rand_bf16((Mbig, K), 1), rand_bf16((N, K), 2, 0.05), rand_bf16((N,), 3, 0.1), rand_bf16((Mbig, N), 4)
