@@ -107,3 +107,32 @@ def test_staggered_pipeline_short_run_drains(dev, split):
     for (i, p), o in zip(batches, outs):
         want = eng.generate(i.to(dev), p.to(dev)).clone().cpu()
         _check_ids(o.cpu(), want, eng.logits.clone().cpu(), "short run")
+
+
+@pytest.mark.parametrize("n_new", [2, 4])
+def test_staggered_pipeline_other_depths(dev, n_new):
+    """The slot rotation is generic in n_new (slots = n_new, n_new - 1 merged decode groups)."""
+    from bridgelang_amd import weights as W
+    from bridgelang_amd.engine import OpenVLAEngine
+    from bridgelang_amd.pipeline import StaggeredDecodePipeline
+    from test_engine_gpu import make_inputs
+    dims = W.tiny_dims()
+    w = W.allocate(dims, dev).fill_synthetic(seed=3)
+    B, L, n = 2, 9, 7
+    eng = OpenVLAEngine(w, B, L, n_new=n_new)
+    batches = [make_inputs(dims, B, L, seed=s) for s in range(n)]
+    want, want_lg = [], []
+    for i, p in batches:
+        want.append(eng.generate(i.to(dev), p.to(dev)).clone().cpu())
+        want_lg.append(eng.logits.clone().cpu())
+    pipe = StaggeredDecodePipeline(w, B, L, n_new=n_new)
+    assert pipe.slots == n_new and len(pipe.engines) == n_new
+    got = []
+    for k, (i, p) in enumerate(batches):
+        out = pipe.step(i.to(dev), p.to(dev)).clone()
+        if k >= pipe.slots - 1:
+            got.append(out.cpu())
+    got += [o.cpu() for o in pipe.flush()]
+    assert len(got) == n and all(g.shape == (B, n_new) for g in got)
+    for k in range(n):
+        _check_ids(got[k], want[k], want_lg[k], f"n_new={n_new} batch {k}")
