@@ -251,7 +251,7 @@ def main() -> None:
                                                  "batch completes per step",
                                        7: "; 7 batches in flight: per step one batch is submitted (vision+prefill) while decode "
                                           "iteration g of the batch submitted g steps earlier, g = 1..6, runs as ONE merged 96-row "
-                                          "pass over the weights; one batch completes per step"}.get(args.pipeline, "8 in flight")),
+                                          "pass over the weights (bit-identical to per-batch decode); one batch completes per step"}.get(args.pipeline, "8 in flight")),
                        "batch_per_gpu": args.batch, "prompt_len": args.prompt_len, "seq_len": eng.S,
                        "replicas": world, "hip_graph": not args.no_graph, "pipeline_depth": args.pipeline},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -273,10 +273,10 @@ def main() -> None:
         }
         if args.pipeline >= 7:   # same inputs in every slot: fraction of sequences whose 7 ids equal the one-batch engine's
             line["end_to_end"]["staggered_ids_equal_one_batch_engine"] = round(pipe_agree, 4)
-            line["end_to_end"]["staggered_ids_note"] = ("random-init weights give nearly flat logits: the merged decode pass (tiled GEMM "
-                                                       "instead of the weight-streaming kernel, other fp32 summation order) flips greedy "
-                                                       "tokens only where the top-2 gap is inside bf16 noise — every divergence is checked "
-                                                       "against that gap in tests/test_full_size_gpu.py::test_staggered_pipeline_full_size")
+            line["end_to_end"]["staggered_ids_note"] = ("the merged 96-row decode pass runs bl_gemm_skinny_rows_bf16 + bl_rmsnorm_skinny_bf16, "
+                                                       "which reproduce the per-batch weight-streaming kernels' fp32 summation order: ids "
+                                                       "and logits are bit-identical to the one-batch engine "
+                                                       "(tests/test_full_size_gpu.py::test_staggered_pipeline_full_size)")
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would wait at the barrier)
             line["cpu_baseline"] = cpu_baseline(dims, args.batch, args.prompt_len)
         print(json.dumps(line), flush=True)

@@ -297,6 +297,25 @@ __global__ __launch_bounds__(256) void gemm128_splitk_reduce_kernel(GemmArgs p) 
 #endif
 }
 
+// out(m, n..n+3) = epilogue(tree of the S = 2 / 4 / 8 slab partials) for gemm_mid_kernel<SK>: the upper levels of the
+// skinny order's balanced binary tree (each partial is already the tree value of an aligned group of 8/S slices)
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_rows_tree_reduce_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int n4 = p.N >> 2, S = p.splitk;
+  const long total = (long)p.M * n4, stride = (long)p.M * p.N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
+    const float* q = p.slab + (long)m * p.N + n;
+    f32x4_t v[8];
+    for (int s2 = 0; s2 < S; ++s2) v[s2] = *(const f32x4_t*)(q + s2 * stride);
+    for (int w = 1; w < S; w *= 2)
+      for (int s2 = 0; s2 < S; s2 += 2 * w) v[s2] = v[s2] + v[s2 + w];
+    epilogue_store4<EPI>(p, m, n, v[0]);
+  }
+#endif
+}
+
 // ======================================================================================================================
 // "mid" kernel: ALL M ≤ 64·MB rows × (16·NB) columns per workgroup (batch-1 prefill S = 288, one image's ViT tokens, the
 // projector at one image): every weight byte leaves HBM exactly once per GEMM — these shapes are bound by the weight
@@ -307,8 +326,18 @@ __global__ __launch_bounds__(256) void gemm128_splitk_reduce_kernel(GemmArgs p) 
 // tile kernels' (K-tile by K-tile, two 32-steps each), so results are bit-identical to theirs — a sequence's result does
 // not depend on the batch size it was run in. grid.y may slice K when the caller provides a workspace (opt-in).
 // ======================================================================================================================
-template <int EPI, int MB, int NB>
-__global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs p) {
+//
+// SK > 0 ("skinny order", bl_gemm_skinny_rows_bf16): the fp32 summation order of gemm_skinny_kernel instead of the tile
+// kernels' — K is cut into 8 slices of p.fold_ks MFMA k-steps; each slice is accumulated from zero in k order; the slice
+// partials are combined as a balanced binary tree ((p0+p1)+(p2+p3))+((p4+p5)+(p6+p7)). A workgroup walks SK consecutive
+// slices (SK = 8: all of K; SK = 2 with grid.y = 4 for the narrow layers, whose 64 column slabs alone would leave 3/4 of
+// the CUs idle) and folds finished slices into a binary-counter stack of held partial sums (log2 SK accumulator sets),
+// so an aligned group of slices yields exactly its subtree's value; grid.y > 1 writes that value as an fp32 partial and
+// gemm_rows_tree_reduce_kernel finishes the tree. Every row's result is bit-identical to what the weight-streaming
+// kernel gives that row in a batch of <= 16, whatever the grid (the merged decode iteration of StaggeredDecodePipeline
+// stacks 6 such batches and streams the weights once).
+template <int EPI, int MB, int NB, int SK = 0>
+__global__ __launch_bounds__(256, 2) void gemm_mid_kernel(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 64 * MB, BN = 16 * NB, NWAVE = 4, NST = 3;
   constexpr int A_BYTES = BM * ROW_BYTES, BUF_BYTES = A_BYTES + NB * 2048;
@@ -361,14 +390,20 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs p) {
   const int offW = A_BYTES + lane * 16;                 // block i*2 + ks
 
   f32x4_t acc[NB][MB];
+  constexpr int LV = SK >= 8 ? 3 : SK >= 4 ? 2 : SK >= 2 ? 1 : 0;   // levels of held partial sums
+  f32x4_t hold[LV ? LV : 1][SK ? NB : 1][SK ? MB : 1];
 #pragma unroll
   for (int i = 0; i < NB; ++i)
 #pragma unroll
     for (int j = 0; j < MB; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  int fold_next = p.fold_ks, sl = 0;        // SK: k-step count at which the current slice ends; local slice index
 
   const int nk_all = p.K / BK;
   int kt0 = 0, nk = nk_all;
-  if (p.splitk > 1) {
+  if constexpr (SK > 0) {                   // slices [blockIdx.y·SK, +SK): SK even → the range starts on a K-tile
+    kt0 = (int)blockIdx.y * SK * p.fold_ks / 2;
+    nk = kt0 + SK * p.fold_ks / 2;
+  } else if (p.splitk > 1) {
     kt0 = (int)(((long)blockIdx.y * nk_all) / p.splitk);
     nk = (int)(((long)(blockIdx.y + 1) * nk_all) / p.splitk);
   }
@@ -386,25 +421,94 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs p) {
     }
     __builtin_amdgcn_s_barrier();      // every wave's pieces of K-tile kt have landed
     const char* base = smem + (it % NST) * BUF_BYTES;
+    if constexpr (SK == 0) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int cb = (c0 ^ (ks * 4)) << 4;
-      bf16x8_t wf[NB], af[MB];
+      for (int ks = 0; ks < 2; ++ks) {
+        const int cb = (c0 ^ (ks * 4)) << 4;
+        bf16x8_t wf[NB], af[MB];
 #pragma unroll
-      for (int i = 0; i < NB; ++i) wf[i] = *(const bf16x8_t*)(base + offW + (i * 2 + ks) * 1024);
+        for (int i = 0; i < NB; ++i) wf[i] = *(const bf16x8_t*)(base + offW + (i * 2 + ks) * 1024);
 #pragma unroll
-      for (int j = 0; j < MB; ++j) af[j] = *(const bf16x8_t*)(base + offA + j * 16 * ROW_BYTES + cb);
+        for (int j = 0; j < MB; ++j) af[j] = *(const bf16x8_t*)(base + offA + j * 16 * ROW_BYTES + cb);
 #pragma unroll
-      for (int i = 0; i < NB; ++i)
+        for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int j = 0; j < MB; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < MB; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // both k-steps' fragments are read before the first MFMA: the slice-boundary branch between the k-steps would
+      // otherwise keep the second k-step's LDS reads from overlapping the first one's MFMAs
+      bf16x8_t wf[2][NB], af[2][MB];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int cb = (c0 ^ (ks * 4)) << 4;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) wf[ks][i] = *(const bf16x8_t*)(base + offW + (i * 2 + ks) * 1024);
+#pragma unroll
+        for (int j = 0; j < MB; ++j) af[ks][j] = *(const bf16x8_t*)(base + offA + j * 16 * ROW_BYTES + cb);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+          for (int j = 0; j < MB; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
+        if (it * 2 + ks + 1 == fold_next) {       // slice boundary (may fall between the two k-steps of a K-tile)
+          // binary counter over the local slice index sl (wave-uniform → scalar branches): a finished slice is parked at
+          // level 0 or merged upwards while the levels below are occupied; after the group's last slice acc holds the
+          // tree value of the whole group
+          bool parked = false;
+          // opaque to the optimiser: without this hipcc speculates the level-0 add (hold + acc) on EVERY k-step, a VALU
+          // read of the accumulators that drains the MFMA pipeline each time (2x slower)
+#pragma unroll
+          for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < MB; ++j) asm volatile("" : "+v"(acc[i][j]));
+#define BL_FOLD_LEVEL(L)                                                                   \
+  if constexpr (LV > L) {                                                                   \
+    if (!parked) {                                                                          \
+      if (!((sl >> L) & 1)) {                                                               \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                      \
+          _Pragma("unroll") for (int j = 0; j < MB; ++j) hold[L][i][j] = acc[i][j];         \
+        parked = true;                                                                      \
+      } else {                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                      \
+          _Pragma("unroll") for (int j = 0; j < MB; ++j) acc[i][j] = hold[L][i][j] + acc[i][j]; \
+      }                                                                                     \
+    }                                                                                       \
+  }
+          BL_FOLD_LEVEL(0) BL_FOLD_LEVEL(1) BL_FOLD_LEVEL(2)
+#undef BL_FOLD_LEVEL
+          if (parked) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+              for (int j = 0; j < MB; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          }
+          fold_next += p.fold_ks;
+          ++sl;
+        }
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // all reads of this slot done before it is re-issued next iteration
   }
 #undef BL_STAGE
 #undef BL_WAIT_TILES
+  if constexpr (SK > 0) {
+    float* slab = p.slab + (long)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int j = 0; j < MB; ++j) {
+        const int m = wave * 16 * MB + j * 16 + l15, n = n0 + i * 16 + lg * 4;
+        if (gridDim.y == 1) epilogue_store4<EPI>(p, m, n, acc[i][j]);
+        else if (m < p.M && n < p.N) *(f32x4_t*)(slab + (long)m * p.N + n) = acc[i][j];
+      }
+    return;
+  }
   if (p.splitk > 1) {
     float* slab = p.slab + (long)blockIdx.y * p.M * p.N;
 #pragma unroll
@@ -921,10 +1025,37 @@ __global__ __launch_bounds__(512) void gemm_splitk_reduce_kernel(GemmArgs p) {
 
 template <int MB, int NB>
 constexpr int mid_lds_bytes() { return 3 * (64 * MB * ROW_BYTES + NB * 2048); }
-template <int EPI, int MB, int NB>
+template <int EPI, int MB, int NB, int SK = 0>
 bool mid_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mid_kernel<EPI, MB, NB>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mid_kernel<EPI, MB, NB, SK>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, mid_lds_bytes<MB, NB>()) == hipSuccess;
+}
+
+// bl_gemm_skinny_rows_bf16: M <= 128 rows through gemm_mid_kernel in the skinny kernel's summation order
+template <int EPI>
+int launch_rows_sk(const GemmArgs& a, hipStream_t s) {
+  static bool done = false;
+  if (!done) {
+    if (!mid_attr<EPI, 2, 4, 8>() || !mid_attr<EPI, 2, 4, 2>()) return BL_E_LAUNCH;
+    done = true;
+  }
+  GemmArgs p = a;
+  p.fold_ks = p.K / 256;                       // 8 slices of K/8 columns = K/256 MFMA k-steps each
+  const int slabs64 = (p.N + 63) / 64;
+  // 64-column slabs, every weight byte once, all rows of A staged once per workgroup. Where that leaves most CUs without
+  // a workgroup (N = 4096: 64 slabs) and the caller gave a workspace, grid.y = 4 workgroups take two K-slices each and
+  // the tree is finished by the reduce kernel — the split is exact (see gemm_mid_kernel) and the same for every row.
+  const bool split = slabs64 * 2 <= 256 && p.slab && p.slab_bytes >= 4L * p.M * p.N * 4;
+  p.splitk = split ? 4 : 1;
+  if (split) {
+    hipLaunchKernelGGL((gemm_mid_kernel<EPI, 2, 4, 2>), dim3(slabs64, 4), dim3(256), (mid_lds_bytes<2, 4>()), s, p);
+    const long work = (long)p.M * (p.N / 4);
+    hipLaunchKernelGGL((gemm_rows_tree_reduce_kernel<EPI>), dim3((int)min((work + 255) / 256, 2048L)), dim3(256), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((gemm_mid_kernel<EPI, 2, 4, 8>), dim3(slabs64), dim3(256), (mid_lds_bytes<2, 4>()), s, p);
+  }
+  BL_CHECK_LAUNCH();
+  return BL_OK;
 }
 
 template <int EPI>
@@ -1116,6 +1247,23 @@ extern "C" int bl_gemm_bf16(const bl_gemm_desc* d, void* stream) {
     case BL_EPI_SWIGLU: return launch_gemm<BL_EPI_SWIGLU>(a, s);
     case BL_EPI_F32: return launch_gemm<BL_EPI_F32>(a, s);
     case BL_EPI_F32_BF16R: return launch_gemm<BL_EPI_F32_BF16R>(a, s);
+    default: return BL_E_ARG;
+  }
+}
+
+extern "C" int bl_gemm_skinny_rows_bf16(const bl_gemm_desc* d, void* stream) {
+  GemmArgs a;
+  const int rc = fill_gemm_args(d, a);
+  if (rc != BL_OK) return rc;
+  if (d->M > 128 || (d->K % 256) || d->a_norm_weight) return BL_E_SHAPE;   // the norm is its own launch: bl_rmsnorm_skinny_bf16
+  if (d->out_group) return BL_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  switch (d->epilogue) {
+    case BL_EPI_NONE: return launch_rows_sk<BL_EPI_NONE>(a, s);
+    case BL_EPI_RES: return launch_rows_sk<BL_EPI_RES>(a, s);
+    case BL_EPI_SWIGLU: return launch_rows_sk<BL_EPI_SWIGLU>(a, s);
+    case BL_EPI_F32: return launch_rows_sk<BL_EPI_F32>(a, s);
+    case BL_EPI_F32_BF16R: return launch_rows_sk<BL_EPI_F32_BF16R>(a, s);
     default: return BL_E_ARG;
   }
 }

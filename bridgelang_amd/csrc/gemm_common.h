@@ -17,6 +17,7 @@ struct GemmArgs {
   float* slab; long slab_bytes; int splitk;   // split-K tail of the 256x256 kernel (fp32 partial tiles)
   int tail_base;   // >= 0: this launch covers big (256x256) tiles tail_base.. of the tiles_m x tiles_n big-tile grid
   const float* qa; const float* qw;   // fp8 GEMM: per-row activation / per-column weight dequantisation scales
+  int fold_ks;   // gemm_mid_kernel<SK>: MFMA k-steps per K-slice (skinny summation order); 0 = off
 };
 
 __device__ __forceinline__ int out_row_of(const GemmArgs& p, int m) {
@@ -94,6 +95,7 @@ inline int fill_gemm_args(const bl_gemm_desc* d, GemmArgs& a) {
   a.slab = (float*)d->workspace; a.slab_bytes = d->workspace_bytes; a.splitk = 1;
   a.norm_w = d->a_norm_weight; a.norm_eps = d->a_norm_eps;
   a.qa = a.qw = nullptr;
+  a.fold_ks = 0;
   return BL_OK;
 }
 

@@ -12,7 +12,7 @@
 //     stream is the weights: straight HBM→VGPR 16-byte non-temporal loads (no LDS round trip — guide §5 "GEMV / M ≤ 16"
 //     row) in two register buffers of GS loads; `sched_barrier` pins "issue group g+1, then the MFMAs of group g" (left
 //     alone, hipcc collapses the batch to 2 loads in flight), and the prefetch runs across tile boundaries.
-//   * the 8 partial 16×16 fp32 tiles are summed through LDS behind a RAW s_barrier (a __syncthreads() would emit
+//   * the 8 partial 16×16 fp32 tiles are summed (balanced binary tree) through LDS behind a RAW s_barrier (a __syncthreads() would emit
 //     vmcnt(0) and drain the prefetch), double-buffered, and a rotating wave applies the fused epilogue.
 #include "gemm_common.h"
 
@@ -20,6 +20,65 @@ namespace bl_gemm_skinny_impl {
 using namespace blgemm;
 
 constexpr int NW = 8;   // waves per workgroup = K split factor
+
+// lane (l15, lg) of wave `wave` holds x[row0 + l15][kbase + 32*s .. +7] for s < KS (kbase = wave*KS*32 + lg*8)
+template <int KS>
+__device__ __forceinline__ void load_x_fragments(const uint16_t* A, long lda, int M, int l15, long kbase,
+                                                 bf16x8_t (&xf)[KS]) {
+  const bool live = l15 < M;
+  const uint16_t* xp = A + (long)(live ? l15 : M - 1) * lda + kbase;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    u32x4_t t = *(const u32x4_t*)(xp + s * 32);
+    if (!live) t = (u32x4_t){0u, 0u, 0u, 0u};
+    xf[s] = __builtin_bit_cast(bf16x8_t, t);
+  }
+}
+
+// Fused HF LlamaRMSNorm on 16 activation rows held as fragments by the 8 waves of a workgroup: sum of squares over the
+// lane's K positions (explicit FMAs, fixed order), across the 4 lane groups that share a row, then across the 8 waves
+// through LDS in wave order; the fragments are rewritten in registers with HF's two roundings
+// (weight * bf16(x * rstd)). ONE definition shared by the weight-streaming GEMM and bl_rmsnorm_skinny_bf16, so the
+// merged-decode path (norm kernel + bl_gemm_skinny_rows_bf16) reproduces the fused path bit for bit.
+template <int KS>
+__device__ __forceinline__ void rmsnorm_fragments(const uint16_t* norm_w, float eps, int K, long kbase, int wave, int l15,
+                                                  int lg, float (&nrm)[8][16], bf16x8_t (&xf)[KS]) {
+  u32x4_t gw[KS];                       // norm weights for this lane's k positions: issued before the reduction
+  {
+    const uint16_t* wn = norm_w + kbase;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) gw[s] = *(const u32x4_t*)(wn + s * 32);
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const u32x4_t t = __builtin_bit_cast(u32x4_t, xf[s]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ss = __builtin_fmaf(bflo(t[i]), bflo(t[i]), ss);
+      ss = __builtin_fmaf(bfhi(t[i]), bfhi(t[i]), ss);
+    }
+  }
+  ss += __shfl_xor(ss, 16, 64);
+  ss += __shfl_xor(ss, 32, 64);
+  if (lg == 0) nrm[wave][l15] = ss;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // raw barrier: keep prefetched weight loads in flight
+  __builtin_amdgcn_s_barrier();
+  float tot = 0.f;
+#pragma unroll
+  for (int w2 = 0; w2 < 8; ++w2) tot += nrm[w2][l15];
+  const float rstd = 1.0f / sqrtf(__builtin_fmaf(tot, 1.0f / (float)K, eps));
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const u32x4_t t = __builtin_bit_cast(u32x4_t, xf[s]);
+    const u32x4_t g = gw[s];
+    u32x4_t o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      o[i] = pack2bf(bflo(g[i]) * rbf(bflo(t[i]) * rstd), bfhi(g[i]) * rbf(bfhi(t[i]) * rstd));
+    xf[s] = __builtin_bit_cast(bf16x8_t, o);
+  }
+}
 
 // KS = MFMA k-steps (32 wide) per wave: K == NW * KS * 32.  GS = k-steps per load group; G = ceil(KS/GS) must be even
 // so the two register buffers alternate with compile-time indices.
@@ -35,16 +94,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, int n_
   // activation fragments ("B" operand): lane holds x[m = l15][kbase + 32*s .. +7]; rows >= M read row M-1 and are
   // zeroed with a select (no per-load branches)
   bf16x8_t xf[KS];
-  {
-    const bool live = l15 < p.M;
-    const uint16_t* xp = p.A + (long)(live ? l15 : p.M - 1) * p.lda + kbase;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      u32x4_t t = *(const u32x4_t*)(xp + s * 32);
-      if (!live) t = (u32x4_t){0u, 0u, 0u, 0u};
-      xf[s] = __builtin_bit_cast(bf16x8_t, t);
-    }
-  }
+  load_x_fragments<KS>(p.A, p.lda, p.M, l15, kbase, xf);
 
   // packed weights, 16-byte units: block (tile, k-step) = 64 units; this lane's unit = lane
   u32x4_t wbuf[2][GS];
@@ -63,42 +113,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, int n_
   if (tile < n_tiles) BL_LOAD_GROUP(0, tile, 0);   // first weight group is in flight while the norm prologue runs
 
   if constexpr (NORM) {
-    // fused HF LlamaRMSNorm on the activation rows: sum of squares over the wave's K-slice, across the 4 lane groups
-    // that share a row, then across the 8 waves through LDS; the fragments are rewritten in registers with the same
-    // two roundings as bl_rmsnorm_bf16.
     __shared__ float nrm[NW][16];
-    u32x4_t gw[KS];                       // norm weights for this lane's k positions: issued before the reduction
-    {
-      const uint16_t* wn = p.norm_w + kbase;
-#pragma unroll
-      for (int s = 0; s < KS; ++s) gw[s] = *(const u32x4_t*)(wn + s * 32);
-    }
-    float ss = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const u32x4_t t = __builtin_bit_cast(u32x4_t, xf[s]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) ss += bflo(t[i]) * bflo(t[i]) + bfhi(t[i]) * bfhi(t[i]);
-    }
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
-    if (lg == 0) nrm[wave][l15] = ss;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // raw barrier: keep the prefetched weight loads in flight
-    __builtin_amdgcn_s_barrier();
-    float tot = 0.f;
-#pragma unroll
-    for (int w2 = 0; w2 < NW; ++w2) tot += nrm[w2][l15];
-    const float rstd = 1.0f / sqrtf(tot * (1.0f / (float)p.K) + p.norm_eps);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const u32x4_t t = __builtin_bit_cast(u32x4_t, xf[s]);
-      const u32x4_t g = gw[s];
-      u32x4_t o;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        o[i] = pack2bf(bflo(g[i]) * rbf(bflo(t[i]) * rstd), bfhi(g[i]) * rbf(bfhi(t[i]) * rstd));
-      xf[s] = __builtin_bit_cast(bf16x8_t, o);
-    }
+    rmsnorm_fragments<KS>(p.norm_w, p.norm_eps, p.K, kbase, wave, l15, lg, nrm, xf);
   }
 
   for (; tile < n_tiles; tile += gridDim.x, ++it) {
@@ -121,9 +137,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, int n_
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wave == (it % NW)) {
-      f32x4_t sum = red[it & 1][0][lane];
-#pragma unroll
-      for (int w2 = 1; w2 < NW; ++w2) sum += red[it & 1][w2][lane];
+      // balanced binary tree over the 8 slice partials: an aligned group of slices has a value of its own, so the
+      // many-rows form of this arithmetic (bl_gemm_skinny_rows_bf16) may split K across workgroups exactly
+      const f32x4_t (&r)[NW][64] = red[it & 1];
+      const f32x4_t sum = ((r[0][lane] + r[1][lane]) + (r[2][lane] + r[3][lane])) +
+                          ((r[4][lane] + r[5][lane]) + (r[6][lane] + r[7][lane]));
       epilogue_store4<EPI>(p, l15, tile * 16 + lg * 4, sum);
     }
   }
@@ -158,6 +176,35 @@ int launch_skinny(const GemmArgs& a, hipStream_t s) {
   }
 }
 
+
+// RMSNorm of rows in the fused-norm arithmetic of gemm_skinny_kernel: one workgroup per 16 rows, fragments in, fragments
+// out (y may alias x).
+template <int KS>
+__global__ __launch_bounds__(NW * 64) void rmsnorm_skinny_kernel(const uint16_t* x, long ldx, const uint16_t* w,
+                                                                 uint16_t* y, long ldy, int rows, int K, float eps) {
+  __shared__ float nrm[NW][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const long kbase = (long)wave * (KS * 32) + lg * 8;
+  const int row0 = blockIdx.x * 16, m = min(16, rows - row0);
+  bf16x8_t xf[KS];
+  load_x_fragments<KS>(x + (long)row0 * ldx, ldx, m, l15, kbase, xf);
+  rmsnorm_fragments<KS>(w, eps, K, kbase, wave, l15, lg, nrm, xf);
+  if (l15 < m) {
+    uint16_t* yp = y + (long)(row0 + l15) * ldy + kbase;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) *(u32x4_t*)(yp + s * 32) = __builtin_bit_cast(u32x4_t, xf[s]);
+  }
+}
+
+template <int KS>
+int launch_norm_skinny(const uint16_t* x, long ldx, const uint16_t* w, uint16_t* y, long ldy, int rows, int K, float eps,
+                       hipStream_t s) {
+  hipLaunchKernelGGL((rmsnorm_skinny_kernel<KS>), dim3((rows + 15) / 16), dim3(NW * 64), 0, s, x, ldx, w, y, ldy, rows, K, eps);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
 }  // namespace bl_gemm_skinny_impl
 using namespace bl_gemm_skinny_impl;
 
@@ -174,5 +221,24 @@ extern "C" int bl_gemm_skinny_bf16(const bl_gemm_desc* d, void* stream) {
     case BL_EPI_F32: return launch_skinny<BL_EPI_F32>(a, s);
     case BL_EPI_F32_BF16R: return launch_skinny<BL_EPI_F32_BF16R>(a, s);
     default: return BL_E_ARG;
+  }
+}
+
+extern "C" int bl_rmsnorm_skinny_bf16(const bl_bf16* x, int64_t ldx, const bl_bf16* w, bl_bf16* y, int64_t ldy,
+                                      int32_t rows, int32_t dim, float eps, void* stream) {
+  if (!x || !w || !y) return BL_E_ARG;
+  if (rows <= 0) return BL_E_SHAPE;
+  if ((ldx % 8) || (ldy % 8) || ldx < dim || ldy < dim || !bl_aligned16(x) || !bl_aligned16(y) || !bl_aligned16(w))
+    return BL_E_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  switch (dim) {   // the K values gemm_skinny_kernel is instantiated for
+    case 4096: return launch_norm_skinny<16>(x, ldx, w, y, ldy, rows, dim, eps, s);
+    case 11008: return launch_norm_skinny<43>(x, ldx, w, y, ldy, rows, dim, eps, s);
+    case 5120: return launch_norm_skinny<20>(x, ldx, w, y, ldy, rows, dim, eps, s);
+    case 13824: return launch_norm_skinny<54>(x, ldx, w, y, ldy, rows, dim, eps, s);
+    case 512: return launch_norm_skinny<2>(x, ldx, w, y, ldy, rows, dim, eps, s);
+    case 1024: return launch_norm_skinny<4>(x, ldx, w, y, ldy, rows, dim, eps, s);
+    case 1536: return launch_norm_skinny<6>(x, ldx, w, y, ldy, rows, dim, eps, s);
+    default: return BL_E_SHAPE;
   }
 }

@@ -19,7 +19,7 @@ from . import _lib
 from ._lib import (AttnDesc, GemmDesc, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_F32, EPI_F32_BF16R, EPI_NONE,
                    EPI_RES, EPI_SWIGLU)
 
-__all__ = ["Op", "gemm", "gemm_fp8", "quantize_rows_fp8", "quantize_weight_fp8", "pack_weight", "unpack_weight", "cross_entropy", "layernorm", "rmsnorm", "attention", "attention_rope", "attention_decode", "attention_decode_rope", "attention_decode_rope_grouped", "skinny_supported", "rope_kvcache", "embed_splice",
+__all__ = ["Op", "gemm", "gemm_fp8", "quantize_rows_fp8", "quantize_weight_fp8", "pack_weight", "unpack_weight", "cross_entropy", "layernorm", "rmsnorm", "rmsnorm_skinny", "skinny_rows_supported", "attention", "attention_rope", "attention_decode", "attention_decode_rope", "attention_decode_rope_grouped", "skinny_supported", "rope_kvcache", "embed_splice",
            "argmax", "im2col_patch14", "preprocess_u8", "resample_coeffs", "resize_bicubic_u8", "write_prefix_tokens", "fill_synth", "run_all",
            "EPI_NONE", "EPI_BIAS", "EPI_BIAS_GELU", "EPI_BIAS_RES", "EPI_RES", "EPI_SWIGLU", "EPI_F32", "EPI_F32_BF16R"]
 
@@ -84,10 +84,18 @@ def unpack_weight(wp: torch.Tensor) -> torch.Tensor:
     return wp.view(nt, ks, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(nt * 16, ks * 32)
 
 
+SKINNY_K = (512, 1024, 1536, 4096, 5120, 11008, 13824)
+_SKINNY_EPI = (EPI_NONE, EPI_RES, EPI_SWIGLU, EPI_F32, EPI_F32_BF16R)
+
+
 def skinny_supported(M: int, K: int, epilogue: int) -> bool:
     """Shapes the weight-streaming kernel is instantiated for (gemm_skinny.hip::launch_skinny)."""
-    return (M <= 16 and K in (512, 1024, 1536, 4096, 5120, 11008, 13824)
-            and epilogue in (EPI_NONE, EPI_RES, EPI_SWIGLU, EPI_F32, EPI_F32_BF16R))
+    return M <= 16 and K in SKINNY_K and epilogue in _SKINNY_EPI
+
+
+def skinny_rows_supported(M: int, K: int, epilogue: int) -> bool:
+    """Shapes bl_gemm_skinny_rows_bf16 takes: up to 128 stacked rows in the skinny kernel's summation order."""
+    return M <= 128 and K in SKINNY_K and epilogue in _SKINNY_EPI
 
 
 def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, *,
@@ -96,7 +104,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, epilogue: int = EP
          out_map: Optional[Tuple[int, int, int]] = None,
          skinny: Optional[bool] = None, algo_nk: Optional[Tuple[int, int]] = None,
          a_norm: Optional[Tuple[torch.Tensor, float]] = None, workspace: Optional[torch.Tensor] = None,
-         run: bool = True) -> Op:
+         skinny_rows: bool = False, run: bool = True) -> Op:
     """out = epilogue(A @ W.T).  A [M,K] row-major activations; W = PACKED weight [N/16, K/32, 64, 8] (pack_weight);
     out [rows, N] (N/2 for SWIGLU; fp32 for F32*).
 
@@ -105,6 +113,8 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, epilogue: int = EP
     `algo_nk=(N, K)` gives the un-padded logical sizes for FLOP accounting when N or K carry zero padding.
     `a_norm=(weight, eps)` fuses HF LlamaRMSNorm on the rows of A (skinny kernel only: M <= 16).
     `workspace`: optional scratch tensor (>= 64 MiB) enabling the split-K tail of the 256x256 kernel.
+    `skinny_rows=True`: bl_gemm_skinny_rows_bf16 — up to 128 rows in the skinny kernel's arithmetic (row results
+    bit-identical to the M <= 16 kernel; the merged decode iteration of StaggeredDecodePipeline).
     """
     lib = _lib.load()
     _bf16(A, "A"); _bf16(W, "W")
@@ -148,10 +158,16 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, epilogue: int = EP
             raise ValueError("gemm: a_norm (fused RMSNorm) needs the skinny kernel (M <= 16 and a supported K)")
         d.a_norm_weight, d.a_norm_eps = _bf16(a_norm[0], "a_norm weight").data_ptr(), float(a_norm[1])
         keep.append(a_norm[0])
-    fn = lib.bl_gemm_skinny_bf16 if use_skinny else lib.bl_gemm_bf16
+    if skinny_rows:
+        if not skinny_rows_supported(M, K, epilogue) or a_norm is not None or out_map is not None:
+            raise ValueError(f"gemm: skinny_rows needs M <= 128, K in {SKINNY_K}, no a_norm / out_map (M={M}, K={K})")
+        name = "bl_gemm_skinny_rows_bf16"
+    else:
+        name = "bl_gemm_skinny_bf16" if use_skinny else "bl_gemm_bf16"
+    fn = getattr(lib, name)
     # algorithmic work: logical FLOPs; bytes = each operand once + the output once
     esz = 4 if epilogue in (EPI_F32, EPI_F32_BF16R) else 2
-    op = Op("bl_gemm_skinny_bf16" if use_skinny else "bl_gemm_bf16", fn, (C.byref(d),), (d, *keep),
+    op = Op(name, fn, (C.byref(d),), (d, *keep),
             flops=2.0 * M * (algo_nk[0] if algo_nk else N) * (algo_nk[1] if algo_nk else K),
             nbytes=2.0 * (M * K + N * K) + esz * M * n_out)
     if run:
@@ -255,6 +271,19 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, eps: float = 1e
     op = Op("bl_rmsnorm_bf16", lib.bl_rmsnorm_bf16,
             (x.data_ptr(), _rows(x, "x"), _bf16(w, "w").data_ptr(), out.data_ptr(), _rows(out, "out"), rows, dim,
              float(eps)), (x, w, out))
+    if run:
+        op.run()
+    return op
+
+
+def rmsnorm_skinny(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, eps: float = 1e-6, run: bool = True) -> Op:
+    """HF LlamaRMSNorm in the arithmetic of the skinny GEMM's fused a_norm (bl_rmsnorm_skinny_bf16); dim in SKINNY_K."""
+    lib = _lib.load()
+    _bf16(x, "x"); _bf16(out, "out")
+    rows, dim = x.shape
+    op = Op("bl_rmsnorm_skinny_bf16", lib.bl_rmsnorm_skinny_bf16,
+            (x.data_ptr(), _rows(x, "x"), _bf16(w, "w").data_ptr(), out.data_ptr(), _rows(out, "out"), rows, dim,
+             float(eps)), (x, w, out), nbytes=4.0 * rows * dim)
     if run:
         op.run()
     return op

@@ -86,8 +86,8 @@ class StaggeredDecodePipeline:
     (KV caches, ids, prefill activations = one OpenVLAEngine each) holds the batch submitted at step ≡ s (mod n_new); the
     n_new slot rotations are captured as n_new HIP graphs.
 
-    Results per sequence equal the plain engine's up to the fp32 summation order of the decode GEMMs (tiled instead of
-    weight-streaming kernel): same tokens unless the top-2 logit gap is inside bf16 noise (tests/test_pipeline_gpu.py).
+    Results per sequence equal the plain engine's bit for bit: the stacked rows go through kernels that reproduce the
+    per-batch kernels' fp32 summation order (_plan_merged; tests/test_pipeline_gpu.py).
     """
 
     def __init__(self, weights: VLAWeights, batch: int, prompt_len: int, n_new: int = 7, split_vision: bool = False,
@@ -109,8 +109,9 @@ class StaggeredDecodePipeline:
         self.xd, self.hd, self.aod = z(M, d.llm_dim), z(M, d.llm_dim), z(M, d.llm_dim)
         self.qkvd, self.actd = z(M, 3 * d.llm_dim), z(M, d.llm_inter)
         self.logits = z(M, d.vocab, dtype=torch.float32)       # rows (g-1)·B … g·B: decode iteration g of this step
-        # fp32 split-K scratch of the merged decode GEMMs (N = 4096 layers slice K; every row alike → slot-invariant)
-        self.ws = torch.empty(max(32 << 20, 8 * M * d.llm_dim * 4), dtype=torch.uint8, device=dev)
+        # fp32 partials of the merged decode GEMMs of the narrow layers (N = llm_dim: four workgroups share K — an exact
+        # split of the skinny order's binary tree, see bl_gemm_skinny_rows_bf16)
+        self.ws = torch.empty(4 * min(M, 128) * d.llm_dim * 4, dtype=torch.uint8, device=dev)
         self._decode_stream = torch.cuda.Stream(device=dev)
         self._vision_stream = torch.cuda.Stream(device=dev)
         self._main_stream = torch.cuda.Stream(device=dev)    # capture stream (stream priorities were tried: no effect)
@@ -120,18 +121,37 @@ class StaggeredDecodePipeline:
 
     def _plan_merged(self, k: int) -> List[Op]:
         """Decode iteration g = 1 … n_new-1 of the batch in slot (k - g) mod n_new, all in one pass over the weights
-        (the per-batch steps of OpenVLAEngine._plan_decode, modeling_prismatic.py:325-341, stacked on the row axis)."""
+        (the per-batch steps of OpenVLAEngine._plan_decode, modeling_prismatic.py:325-341, stacked on the row axis).
+
+        Every op mirrors the kernel choice OpenVLAEngine._plan_decode makes for ONE batch, in its many-rows form with the
+        same arithmetic: where the engine streams weights through bl_gemm_skinny_bf16 (B <= 16), the stacked rows go
+        through bl_gemm_skinny_rows_bf16 (same 8-way K partition and combine order) and the fused a_norm becomes
+        bl_rmsnorm_skinny_bf16; where the engine falls back to the tiled kernels, so does this plan (no split-K workspace:
+        the tiled kernels' K order does not depend on the row count). Hence ids and logits equal the plain engine's bit
+        for bit (tests/test_pipeline_gpu.py, tests/test_full_size_gpu.py)."""
         d, w, B = self.dims, self.w, self.B
         D, H, hd = d.llm_dim, d.llm_heads, d.head_dim
         e0 = self.engines[0]
-        gm = lambda *a, **kw: ops.gemm(*a, workspace=self.ws, **kw)
+        fused = ops.skinny_supported(B, D, EPI_NONE) and hd == 128       # OpenVLAEngine._plan_decode's condition
+        M = self.xd.shape[0]
+
+        def gm(A, W, out, epi, res=None):
+            """one Linear over the stacked rows, in the arithmetic the engine uses for B rows"""
+            if not ops.skinny_supported(B, A.shape[1], epi):
+                return [ops.gemm(A, W, out, epi, res=res, skinny=False, run=False)]
+            return [ops.gemm(A[r0:r0 + 128], W, out[r0:r0 + 128], epi, res=None if res is None else res[r0:r0 + 128],
+                             skinny_rows=True, workspace=self.ws, run=False) for r0 in range(0, M, 128)]
+
+        def norm(x, wn, out, fused_in_engine):
+            return (ops.rmsnorm_skinny if fused_in_engine else ops.rmsnorm)(x, wn, out, d.rms_eps, run=False)
+
         groups = [(g, self.engines[(k - g - self.lag) % self.slots], slice((g - 1) * B, g * B)) for g in range(1, self.n_new)]
         plan = [ops.embed_splice(e.gen_ids[g - 1].view(B, 1), w.embed, self.xd[r].view(B, 1, D), 0, run=False)
                 for g, e, r in groups]
         for l, lw in enumerate(w.layers):
-            plan.append(ops.rmsnorm(self.xd, lw.ln1, self.hd, d.rms_eps, run=False))
-            plan.append(gm(self.hd, lw.qkv_w, self.qkvd, EPI_NONE, run=False))
-            grouped = hd == 128 and len(groups) <= 8
+            plan.append(norm(self.xd, lw.ln1, self.hd, fused))
+            plan += gm(self.hd, lw.qkv_w, self.qkvd, EPI_NONE)
+            grouped = fused and len(groups) <= 8
             if grouped:     # all decode iterations' attention in one launch
                 plan.append(ops.attention_decode_rope_grouped(
                     self.qkvd, [e.k_cache[l] for _, e, _ in groups], [e.v_cache[l] for _, e, _ in groups], self.aod,
@@ -140,7 +160,7 @@ class StaggeredDecodePipeline:
                 pos = e.S + g - 1
                 if grouped:
                     continue
-                if hd == 128:
+                if fused:
                     plan.append(ops.attention_decode_rope(self.qkvd[r], e.k_cache[l], e.v_cache[l], self.aod[r], e0.cos, e0.sin,
                                                           B=B, H=H, head_dim=hd, pos=pos, run=False))
                 else:
@@ -150,12 +170,12 @@ class StaggeredDecodePipeline:
                     plan.append(ops.attention_decode(self.qkvd[r], e.k_cache[l], e.v_cache[l], self.aod[r], B=B, H=H,
                                                      Skv=pos + 1, head_dim=hd, q_strides=(3 * D, hd, 3 * D), k_strides=cs,
                                                      v_strides=cs, o_strides=(D, hd, D), run=False))
-            plan.append(gm(self.aod, lw.o_w, self.xd, EPI_RES, res=self.xd, run=False))
-            plan.append(ops.rmsnorm(self.xd, lw.ln2, self.hd, d.rms_eps, run=False))
-            plan.append(gm(self.hd, lw.gu_w, self.actd, EPI_SWIGLU, run=False))
-            plan.append(gm(self.actd, lw.down_w, self.xd, EPI_RES, res=self.xd, run=False))
-        plan.append(ops.rmsnorm(self.xd, w.norm, self.hd, d.rms_eps, run=False))
-        plan.append(gm(self.hd, w.lm_head, self.logits, EPI_F32_BF16R, run=False))
+            plan += gm(self.aod, lw.o_w, self.xd, EPI_RES, res=self.xd)
+            plan.append(norm(self.xd, lw.ln2, self.hd, fused))
+            plan += gm(self.hd, lw.gu_w, self.actd, EPI_SWIGLU)
+            plan += gm(self.actd, lw.down_w, self.xd, EPI_RES, res=self.xd)
+        plan.append(norm(self.xd, w.norm, self.hd, ops.skinny_supported(B, D, EPI_F32_BF16R)))   # OpenVLAEngine._head
+        plan += gm(self.hd, w.lm_head, self.logits, EPI_F32_BF16R)
         plan += [ops.argmax(self.logits[r], e.gen_ids[g], run=False) for g, e, r in groups]
         return plan
 

@@ -102,6 +102,21 @@ int bl_gemm_bf16(const bl_gemm_desc* d, void* stream);
  * cached-decode branch (modeling_prismatic.py:325-341). */
 int bl_gemm_skinny_bf16(const bl_gemm_desc* d, void* stream);
 
+/* The skinny kernel's arithmetic for 16 < M <= 128 stacked rows: the same 8-way K partition (slice w = K/8 contiguous
+ * columns), the same per-slice k order on the MFMA, the same slice-order fp32 combine and fused epilogue, so every row's
+ * result is bit-identical to bl_gemm_skinny_bf16 on that row alone — whatever batch or row position it is computed in.
+ * Used by the merged decode iteration of StaggeredDecodePipeline (the decode steps of n_new-1 batches stacked into one
+ * pass over the weights; same nn.Linear modules on the cached-decode branch, modeling_prismatic.py:325-341).
+ * K % 256 == 0; epilogues as bl_gemm_skinny_bf16; no out_map, no fused a_norm (see bl_rmsnorm_skinny_bf16). */
+int bl_gemm_skinny_rows_bf16(const bl_gemm_desc* d, void* stream);
+
+/* HF LlamaRMSNorm (transformers modeling_llama.py LlamaRMSNorm.forward; called per decoder layer from the cached-decode
+ * branch, modeling_prismatic.py:325-341) in exactly the arithmetic of bl_gemm_skinny_bf16's fused a_norm (same
+ * sum-of-squares order, same two roundings): y = bf16(w * bf16(x * rsqrt(mean(x^2) + eps))). dim in {512, 1024, 1536,
+ * 4096, 5120, 11008, 13824}. norm kernel + bl_gemm_skinny_rows_bf16 == bl_gemm_skinny_bf16 with a_norm, bit for bit. */
+int bl_rmsnorm_skinny_bf16(const bl_bf16* x, int64_t ldx, const bl_bf16* w, bl_bf16* y, int64_t ldy, int32_t rows,
+                           int32_t dim, float eps, void* stream);
+
 /* ---- FP8 (OCP e4m3) GEMM family — BASELINE configs[4] "fp8 MFMA GEMMs"; the reference has no fp8 path ------------- */
 /* C = epilogue(scale_a[m] * scale_w[n] * (A8 @ W8^T)) on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales, 2x the
  * bf16 MFMA rate). d->A: e4m3 codes [M, K] (lda in bytes, % 16), d->W: e4m3 weight in the fragment-major packing of

@@ -67,3 +67,64 @@ def test_attention_decode_rope(dev, pos):
                          k_strides=cs, v_strides=cs, o_strides=(D, hd, D))
     assert torch.equal(KC.cpu(), KC2.cpu()) and torch.equal(VC.cpu(), VC2.cpu())
     close_bf16(o, o2.cpu().float(), "fused vs unfused decode attention", rtol=2 ** -6, min_exact=0.9)
+
+
+@pytest.mark.parametrize("M,N,K", [(96, 4096, 4096), (96, 1024, 11008), (17, 512, 512), (128, 3072, 1536), (40, 2048, 1024),
+                                   (112, 640, 5120), (96, 256, 13824), (33, 22016, 512)])
+def test_skinny_rows_bit_identical_to_skinny(dev, M, N, K):
+    """bl_gemm_skinny_rows_bf16 (up to 128 stacked rows, the merged decode iteration) must give every row EXACTLY what
+    bl_gemm_skinny_bf16 gives that row in a batch of <= 16 — same 8-way K partition, per-slice k order and combine order
+    — for every epilogue the decode path uses; and against the oracle to bf16 rounding."""
+    from bridgelang_amd import ops
+    a, w, r = rand_bf16((M, K), 1), rand_bf16((N, K), 2, 0.05), rand_bf16((M, N), 4)
+    A, W, Rr = dv(a, dev), pk(w, dev), dv(r, dev)
+    I = N // 2
+    Wgu = pk(torch.stack([w[:I], w[I:]], 1).reshape(N, K), dev)
+    cases = [("NONE", ops.EPI_NONE, W, torch.bfloat16, N, None), ("RES", ops.EPI_RES, W, torch.bfloat16, N, Rr),
+             ("SWIGLU", ops.EPI_SWIGLU, Wgu, torch.bfloat16, I, None), ("F32_BF16R", ops.EPI_F32_BF16R, W, torch.float32, N, None),
+             ("F32", ops.EPI_F32, W, torch.float32, N, None)]
+    ws = torch.empty(4 * M * N * 4, dtype=torch.uint8, device=dev)
+    for name, epi, Wp, dt, n_out, res in cases:
+        got = torch.full((M, n_out), 7.0, dtype=dt, device=dev)
+        ops.gemm(A, Wp, got, epi, res=res, skinny_rows=True)              # one workgroup walks all 8 K-slices
+        got4 = torch.full((M, n_out), 7.0, dtype=dt, device=dev)
+        ops.gemm(A, Wp, got4, epi, res=res, skinny_rows=True, workspace=ws)   # narrow N: K split over 4 workgroups + tree reduce
+        assert torch.equal(got, got4), f"{name}: the K split across workgroups changed {(got != got4).sum().item()} elements"
+        want = torch.empty_like(got)
+        for r0 in range(0, M, 16):      # the per-batch kernel, 16 rows (one batch) at a time; odd group sizes too
+            r1 = min(M, r0 + (16 if r0 % 32 == 0 else 5))
+            for q0, q1 in ((r0, r1), (r1, min(M, r0 + 16))):
+                if q1 > q0:
+                    ops.gemm(A[q0:q1], Wp, want[q0:q1], epi, res=None if res is None else res[q0:q1], skinny=True)
+        assert torch.equal(got, want), f"{name}: {(got != want).sum().item()} of {got.numel()} elements differ"
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(A, W, out, ops.EPI_NONE, skinny_rows=True)
+    close_bf16(out, R.linear(P, a, w), "skinny rows vs oracle")
+
+
+@pytest.mark.parametrize("rows,K", [(96, 4096), (16, 512), (33, 1536), (5, 11008), (50, 5120), (128, 1024), (17, 13824)])
+def test_rmsnorm_skinny_equals_fused_norm(dev, rows, K):
+    """bl_rmsnorm_skinny_bf16 + a GEMM == the skinny GEMM's fused a_norm, bit for bit (probed through an identity-like
+    weight: y = x_norm · Iᵀ returns the normalised activations exactly), and within bf16 rounding of the oracle."""
+    from bridgelang_amd import ops
+    x, g = rand_bf16((rows, K), 1, 3.0), P.rb(rand_bf16((K,), 2, 0.02) + 1)
+    X, G = dv(x, dev), dv(g, dev)
+    h = torch.empty_like(X)
+    ops.rmsnorm_skinny(X, G, h, 1e-6)
+    close_bf16(h, R.rmsnorm(P, x, g, 1e-6), "rmsnorm_skinny vs oracle")
+    n_probe = 512
+    cols = torch.randperm(K, generator=torch.Generator().manual_seed(3))[:n_probe]
+    eye = torch.zeros(n_probe, K)
+    eye[torch.arange(n_probe), cols] = 1.0
+    Wp = pk(eye, dev)
+    w2 = pk(rand_bf16((256, K), 5, 0.05), dev)
+    for r0 in range(0, rows, 16):
+        r1 = min(rows, r0 + 16)
+        fused = torch.empty(r1 - r0, n_probe, dtype=torch.bfloat16, device=dev)
+        ops.gemm(X[r0:r1], Wp, fused, ops.EPI_NONE, a_norm=(G, 1e-6))
+        assert torch.equal(fused, h[r0:r1][:, cols.to(dev)]), "normalised activations differ from the fused norm's"
+        a = torch.empty(r1 - r0, 256, dtype=torch.bfloat16, device=dev)
+        b = torch.empty_like(a)
+        ops.gemm(X[r0:r1], w2, a, ops.EPI_NONE, a_norm=(G, 1e-6))
+        ops.gemm(h[r0:r1], w2, b, ops.EPI_NONE, skinny=True)
+        assert torch.equal(a, b)
