@@ -8,9 +8,16 @@ steps; weights are seeded-synthetic bf16 (no checkpoint exists offline).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...     (N > 1: one replica per GPU)
+    python bench.py --mode train --stage vla-full-train|vla-train|lora [--gpus N]     (BASELINE configs[2] / [3])
+
+`--gpus N` with N > 1 and no torchrun environment: this process — before it touches the GPU — starts N children (one per
+GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) and relays rank 0's JSON line; under torchrun
+the ranks already exist and `--gpus` must equal WORLD_SIZE.
 
 Inference shards by sequence with no exchange step ("replicas only"): every rank runs its own batch, the
-timed region is bracketed by barrier + synchronize, the elapsed time is the MAX over ranks.
+timed region is bracketed by barrier + synchronize, the elapsed time is the MAX over ranks. Training shards the batch
+by rank with the optimizer state partitioned (training/sharding.py: reduce-scatter of gradient buckets overlapped with
+the backward, all-gather of updated weights) — RCCL over xGMI.
 
 Rank 0 prints ONE JSON line with `roofline` (dominant kernel = the tiled MFMA GEMM, measured live with HIP events on the
 launch stream) and `cpu_baseline` (the CPU oracle timed on this host's cores on a bounded, stated sample).
@@ -19,6 +26,9 @@ from __future__ import annotations
 
 import argparse
 import json
+import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -39,16 +49,49 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=None, help="per GPU; default 16 (infer, lora) / 32 (full fine-tune, conf/vla.py:83)")
     ap.add_argument("--prompt-len", type=int, default=32)
     ap.add_argument("--model", default="openvla-7b", choices=["openvla-7b", "openvla-tiny", "prism-13b"])
     ap.add_argument("--no-graph", action="store_true", help="replay the op plan eagerly instead of as one HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp8", action="store_true", help="Llama prefill projections as W8A8 e4m3 GEMMs (BASELINE configs[4] extension; not the bf16 headline)")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="train: one optimisation step of run_vla_training per bench step (BASELINE configs[2] / [3])")
+    ap.add_argument("--stage", default="vla-full-train", choices=["vla-full-train", "vla-train", "lora"],
+                    help="--mode train: full fine-tune (configs[2]), vision frozen, or LoRA r=32 (configs[3])")
+    ap.add_argument("--reduce", default="fp32", choices=["fp32", "bf16"], help="--mode train: gradient wire format")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / fence / JSON plumbing only (gloo, no GPU, a sleep per step): the CPU test of --gpus N")
     ap.add_argument("--pipeline", type=int, default=7, choices=[1, 2, 7, 8],
                     help="2 = overlap batch i's decode with batch i+1's vision+prefill (TwoStagePipeline); 7 = StaggeredDecodePipeline "
                          "(one merged decode iteration over the 6 older batches per step)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 32 if (args.mode == "train" and args.stage != "lora") else 16
+    return args
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int) -> int:
+    """Parent of a `--gpus N` run without torchrun: N children of this same command line, one per GPU. The parent makes
+    no GPU call (a process that has initialised the GPU must not be replaced or forked on this pool); it relays rank 0's
+    stdout (the JSON line) and every rank's stderr, and exits with the worst child status."""
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, str(Path(__file__).resolve())] + sys.argv[1:]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL) for r in range(n)]
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for ln in out.decode().splitlines():          # stdout carries exactly the JSON line; library chatter goes to stderr
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def make_inputs(B: int, L: int, seed: int, device):
@@ -162,15 +205,152 @@ def cpu_baseline(dims, B: int, L: int) -> dict:
                        f"x{n_dec + 1}; extrapolated {per_seq:.1f} s per sequence")}
 
 
+def dry_run(args, rank: int, world: int) -> None:
+    """The launch contract without a GPU: rendezvous (gloo), warm-up, EXACTLY K timed 'steps' (a 10 ms sleep each)
+    between fences, max over ranks, one JSON line from rank 0."""
+    from bridgelang_amd import replicas
+    distributed = replicas.init("gloo")
+    for _ in range(args.warmup):
+        time.sleep(0.01)
+    replicas.fence(None)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (1 + rank))            # the slowest rank sets the time
+    replicas.fence(None)
+    elapsed = replicas.max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run steps/s", "value": round(world * args.batch * args.steps / elapsed, 3), "unit": "items/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "none", "config": {"workload": "dry-run", "mode": args.mode}}),
+              flush=True)
+    if distributed:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def train_main(args, rank: int, world: int, dev, distributed: bool) -> None:
+    """BASELINE configs[2] (full fine-tune, per-GPU batch 32, S = 296, sharded optimizer over the ranks) / configs[3]
+    (LoRA r = 32, batch 16): one `run_vla_training` iteration per step — forward, backward (bucket reduce-scatter
+    overlapped), global-norm clip, AdamW, weight re-pack / all-gather (base_strategy.py:284-366, fsdp.py:135-270)."""
+    from bridgelang_amd import replicas, weights as W
+    from bridgelang_amd.training.step import TrainStep
+    dims = {"openvla-7b": W.openvla_7b_dims, "prism-13b": W.prism_13b_dims, "openvla-tiny": W.tiny_dims}[args.model]()
+    w = W.allocate(dims, dev).fill_synthetic(seed=0)
+    lora = None
+    if args.stage == "lora":
+        from bridgelang_amd.training.lora import LoraAdapters
+        lora = LoraAdapters(w, r=32)
+    B, L = args.batch, args.prompt_len + 8                # 32 prompt ids + 7 action ids + EOS (SURVEY §8d cfg 3 / 4)
+    ts = TrainStep(w, args.stage, B, L, max_grad_norm=1.0 if lora is None else float("inf"),
+                   weight_decay=0.0 if lora is None else 0.01, lora=lora, world=world, rank=rank,
+                   reduce_dtype=torch.float32 if args.reduce == "fp32" else torch.bfloat16)
+    g = torch.Generator().manual_seed(100 + rank)         # each rank draws its own stream (base_strategy.py:259-266)
+    ids = torch.randint(3, 31000, (B, L), generator=g)
+    ids[:, 0] = 1
+    ids[:, -8:-1] = torch.randint(31744, 32000, (B, 7), generator=g)
+    ids[:, -1] = 2
+    labels = torch.full((B, L), -100)
+    labels[:, -8:] = ids[:, -8:]
+    img = torch.randint(0, 256, (B, 224, 224, 3), generator=g, dtype=torch.uint8).float().div_(255.0).permute(0, 3, 1, 2)
+    m = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    sd = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    pv = torch.cat([(img - m) / sd, (img - 0.5) / 0.5], dim=1).to(torch.bfloat16)
+    ts.set_batch(ids, None, pv, labels)                   # batch resident in HBM before the timed region
+    lr = 2e-5 if lora is None else 5e-4
+    graph = not args.no_graph and world == 1              # sharded runs keep the backward eager (per-bucket collectives)
+    losses = []
+    for _ in range(max(args.warmup, 1)):
+        loss, _ = ts.step(lr, graph=graph)
+        losses.append(float(loss.item()))
+    replicas.fence(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = ts.step(lr, graph=graph)
+    replicas.fence(dev)
+    elapsed = replicas.max_over_ranks(time.perf_counter() - t0, dev)
+    losses.append(float(loss.item()))
+    if rank == 0:
+        # per-phase and GEMM-family timing: one instrumented eager step outside the timed region (HIP events on the
+        # launch stream); roofline = the tiled MFMA GEMM family (forward, dgrad, wgrad) per bl_gemm_bf16 call
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        e = [ev() for _ in range(4)]
+        torch.cuda.synchronize()
+        e[0].record(); ts.forward(False)
+        e[1].record(); ts.backward(False)
+        e[2].record(); ts.clip_grad_norm(); ts.optimizer_step(lr, False)
+        e[3].record()
+        torch.cuda.synchronize()
+        phases = {k: round(e[i].elapsed_time(e[i + 1]), 3) for i, k in enumerate(("forward", "backward", "clip+adamw+repack"))}
+        plan = list(ts.vision_forward_ops) + list(ts.forward_ops) + list(ts.backward_ops)
+        if not ts.train_vision:
+            plan = list(ts._vis.vision_ops) + plan
+        stream = torch.cuda.current_stream()
+        evs = [ev() for _ in range(len(plan) + 1)]
+        sptr = stream.cuda_stream
+        evs[0].record(stream)
+        for i, op in enumerate(plan):
+            assert op.fn(*op.args, sptr) == 0, op.name
+            evs[i + 1].record(stream)
+        torch.cuda.synchronize()
+        agg: dict = {}
+        for i, op in enumerate(plan):
+            a = agg.setdefault(op.name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            a["launches"] += 1; a["ms"] += evs[i].elapsed_time(evs[i + 1]); a["flops"] += op.flops
+        gemm = agg["bl_gemm_bf16"]
+        achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
+        model_flops = sum(op.flops for op in plan)
+        ms = elapsed / args.steps * 1e3
+        cfg_no = 3 if args.stage == "lora" else 2
+        line = {
+            "metric": f"samples/sec {dims.name} {args.stage} bf16", "value": round(world * B * args.steps / elapsed, 3), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": (f"{dims.name} {args.stage} (BASELINE configs[{cfg_no}]): per-GPU batch {B} x S={ts.S} "
+                                    f"DummyDataset-shaped samples (32 prompt ids + 7 action ids + EOS, 224px frame), forward + "
+                                    f"backward + global-norm clip + AdamW" + (" on LoRA r=32 adapters" if lora is not None else "")
+                                    + (f"; optimizer state sharded over {world} ranks, {args.reduce} gradient reduce-scatter "
+                                       f"per bucket overlapped with backward, bf16 weight all-gather" if world > 1 else "")),
+                       "batch_per_gpu": B, "global_batch": B * world, "seq_len": ts.S, "stage": args.stage,
+                       "parallelism": f"dp{world} sharded-optimizer (shard-grad-op)" if world > 1 else "single GPU",
+                       "hip_graph": graph},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "tiled MFMA GEMM family (forward, dgrad, wgrad) per bl_gemm_bf16 call",
+                         "launches_per_step": gemm["launches"], "avg_launch_us": round(gemm["ms"] * 1e3 / gemm["launches"], 2),
+                         "algorithmic_gflop_per_launch": round(gemm["flops"] / gemm["launches"] / 1e9, 3)},
+            "end_to_end": {"model_tflop_per_step_per_gpu": round(model_flops / 1e12, 2),
+                           "mfma_util_whole_step": round(model_flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                           "phases_ms_eager_events": phases,
+                           "per_kernel_ms": {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
+                           "trainable_params_B": round(ts.store.n_params / 1e9, 3),
+                           "hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                           "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)]},
+        }
+        print(json.dumps(line), flush=True)
+    if distributed:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main() -> None:
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))          # parent: no GPU call before or after this line
     from bridgelang_amd import replicas
     rank, local, world = replicas.env_rank()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself)")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    distributed = replicas.init("nccl", dev)      # RCCL; only the timing fence uses it (replicas, no data-path collective)
+    distributed = replicas.init("nccl", dev)      # RCCL; inference: only the timing fence uses it (replicas, no data-path collective)
+    if args.mode == "train":
+        return train_main(args, rank, world, dev, distributed)
 
     from bridgelang_amd import weights as W
     from bridgelang_amd.engine import OpenVLAEngine

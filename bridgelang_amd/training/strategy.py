@@ -205,6 +205,9 @@ class ShardedOptimizerStrategy:
             return None
         hf = {} if only_trainable else {k: v.float().cpu() for k, v in self.vlm.weights.state_dict().items()}
         hf.update({k: v.cpu() for k, v in masters.items()})
+        # never-executed tensors of a saved module (last ViT block, final norm, attention pool): the reference loads each
+        # module's state dict strictly (prismatic.py:113-116), so they travel with it
+        hf.update({k: v.float().cpu() for k, v in self.vlm.weights.passthrough.items() if k not in hf})
         keys = self.trainable_module_keys if only_trainable else self.all_module_keys
         model_state_dicts = to_model_state_dicts(hf, keys)
         checkpoint_dir = Path(run_dir) / "checkpoints"

@@ -9,8 +9,9 @@ Device layout (one bf16 arena, 256-byte aligned sub-tensors; 15 GB at 7B — a f
     row end; the pad is zero and never leaves HBM/LDS.
   * Llama q/k/v stacked into one [3D, D] matrix; gate/up interleaved row-wise (2j = gate_j, 2j+1 = up_j) so the SwiGLU
     epilogue finds each (gate, up) pair in one lane.
-  * only blocks up to the tap (n = depth-2, modeling_prismatic.py:85-87,99-101) are materialised: the last ViT block,
-    final norm and SigLIP attention-pool head never run on this path.
+  * only blocks up to the tap (n = depth-2, modeling_prismatic.py:85-87,99-101) are in the arena: the last ViT block,
+    final norm and SigLIP attention-pool head never run on this path. They are kept as pass-through
+    tensors (`passthrough_specs`) so that state dicts written here carry every key the reference loads strictly.
 """
 from __future__ import annotations
 
@@ -114,6 +115,11 @@ class TensorSpec:
     shape: Tuple[int, ...]
     mean: float
     std: float
+    base: Optional[str] = None     # overlay specs only: the tensor whose rows [row0, row0 + shape[0]) this block replaces
+    row0: int = 0
+
+
+RECIPES = ("init", "decisive")
 
 
 def tensor_seed(name: str, seed: int) -> int:
@@ -129,6 +135,12 @@ def _tower_specs(t: TowerDims) -> Iterator[TensorSpec]:
     yield TensorSpec(f"{p}.patch_embed.proj.weight", (D, 3, 14, 14), 0.0, 0.02)
     yield TensorSpec(f"{p}.patch_embed.proj.bias", (D,), 0.0, 0.02)
     for i in range(t.n_run):
+        yield from _block_specs(t, i)
+
+
+def _block_specs(t: TowerDims, i: int) -> Iterator[TensorSpec]:
+    p, D = t.prefix, t.dim
+    if True:
         b = f"{p}.blocks.{i}"
         yield TensorSpec(f"{b}.norm1.weight", (D,), 1.0, 0.02)
         yield TensorSpec(f"{b}.norm1.bias", (D,), 0.0, 0.02)
@@ -148,10 +160,42 @@ def _tower_specs(t: TowerDims) -> Iterator[TensorSpec]:
             yield TensorSpec(f"{b}.ls2.scale_factor", (D,), 0.1, 0.02)
 
 
-def tensor_specs(d: VLADims) -> List[TensorSpec]:
+def passthrough_specs(d: VLADims) -> List[TensorSpec]:
+    """Tensors of the checkpoint that the path never executes but that the reference's modules own and load STRICTLY
+    (prismatic.py:113-116, convert_openvla_weights_to_hf.py:236): the last block of each timm tower (the tap is block
+    depth-2, modeling_prismatic.py:85-87,99-101), the towers' final `norm`, and SigLIP's attention-pool head
+    (`global_pool='map'`, timm 0.9.10 AttentionPoolLatent — † names from knowledge of timm, unverifiable offline, SURVEY
+    App. A.1). They are held beside the arena, round-tripped by load_state_dict / state_dict, and never read by a kernel."""
+    out: List[TensorSpec] = []
+    for t in (d.dino, d.siglip):
+        out += list(_block_specs(t, t.depth - 1))
+        out += [TensorSpec(f"{t.prefix}.norm.weight", (t.dim,), 1.0, 0.02), TensorSpec(f"{t.prefix}.norm.bias", (t.dim,), 0.0, 0.02)]
+    t, ap = d.siglip, f"{d.siglip.prefix}.attn_pool"
+    D = t.dim
+    out += [TensorSpec(f"{ap}.latent", (1, 1, D), 0.0, 0.02),
+            TensorSpec(f"{ap}.q.weight", (D, D), 0.0, 0.02), TensorSpec(f"{ap}.q.bias", (D,), 0.0, 0.02),
+            TensorSpec(f"{ap}.kv.weight", (2 * D, D), 0.0, 0.02), TensorSpec(f"{ap}.kv.bias", (2 * D,), 0.0, 0.02),
+            TensorSpec(f"{ap}.proj.weight", (D, D), 0.0, 0.02), TensorSpec(f"{ap}.proj.bias", (D,), 0.0, 0.02),
+            TensorSpec(f"{ap}.norm.weight", (D,), 1.0, 0.02), TensorSpec(f"{ap}.norm.bias", (D,), 0.0, 0.02),
+            TensorSpec(f"{ap}.mlp.fc1.weight", (t.mlp, D), 0.0, 0.02), TensorSpec(f"{ap}.mlp.fc1.bias", (t.mlp,), 0.0, 0.02),
+            TensorSpec(f"{ap}.mlp.fc2.weight", (D, t.mlp), 0.0, 0.02), TensorSpec(f"{ap}.mlp.fc2.bias", (D,), 0.0, 0.02)]
+    return out
+
+
+def tensor_specs(d: VLADims, recipe: str = "init") -> List[TensorSpec]:
     """Every tensor the path reads, under its HF state-dict name, with the synthetic distribution that stands in for the
     checkpoint (normal(0, 0.02) weights as in modeling_prismatic.py:185-205; norm scales around 1; LayerScale around 0.1
-    so the DINOv2 branches stay visible in the output — SURVEY §8d's 1e-5 init would hide them from every parity test)."""
+    so the DINOv2 branches stay visible in the output — SURVEY §8d's 1e-5 init would hide them from every parity test).
+
+    recipe="init" is the bench checkpoint. recipe="decisive" is a second synthetic checkpoint for id-exact
+    parity tests at full size: a freshly initialised 32-layer decoder is chaotic (every residual branch is as large as
+    the stream it is added to, so bf16 rounding noise grows to percents of the logit scale and the 32064 logits are flat),
+    which a trained checkpoint is not. It differs from "init" in three std values: residual-branch output projections
+    (attn.proj / mlp.fc2 / o_proj / down_proj) are scaled by 1/sqrt(2·depth) (GPT-2 style), token embeddings have unit
+    std (they then carry the stream), and — as an overlay, synthetic_overlays() — the lm_head rows of the 256 action
+    tokens are 6x larger, so greedy decoding lands in the action vocabulary as a fine-tuned OpenVLA does."""
+    if recipe not in RECIPES:
+        raise ValueError(f"unknown synthetic recipe {recipe!r}")
     out = list(_tower_specs(d.dino)) + list(_tower_specs(d.siglip))
     V, P, L = d.vision_dim, 4 * d.vision_dim, d.llm_dim
     out += [TensorSpec("projector.fc1.weight", (P, V), 0.0, 0.02), TensorSpec("projector.fc1.bias", (P,), 0.0, 0.02),
@@ -170,7 +214,31 @@ def tensor_specs(d: VLADims) -> List[TensorSpec]:
         out.append(TensorSpec(f"{b}.mlp.down_proj.weight", (L, d.llm_inter), 0.0, 0.02))
     out.append(TensorSpec(f"{lm}.norm.weight", (L,), 1.0, 0.02))
     out.append(TensorSpec("language_model.lm_head.weight", (d.vocab, L), 0.0, 0.02))
+    if recipe == "decisive":
+        depth = {d.dino.prefix: d.dino.n_run, d.siglip.prefix: d.siglip.n_run, "language_model": d.llm_layers}
+
+        def adjust(sp: TensorSpec) -> TensorSpec:
+            if sp.name.endswith((".attn.proj.weight", ".mlp.fc2.weight", ".o_proj.weight", ".down_proj.weight")):
+                n = next(v for k, v in depth.items() if sp.name.startswith(k))
+                return TensorSpec(sp.name, sp.shape, sp.mean, sp.std / (2.0 * n) ** 0.5)
+            if sp.name.endswith("embed_tokens.weight"):
+                return TensorSpec(sp.name, sp.shape, 0.0, 1.0)
+            return sp
+        out = [adjust(sp) for sp in out]
     return out
+
+
+N_ACTION_TOKENS = 256      # OpenVLAConfig.n_action_bins (configuration_prismatic.py:134): ids vocab_size-256 .. vocab_size-1
+TOKENIZER_VOCAB = 32000    # Llama-2 tokenizer size; the padded embedding has d.vocab = 32064 rows
+
+
+def synthetic_overlays(d: VLADims, recipe: str = "init") -> List[TensorSpec]:
+    """Row blocks generated separately and written over part of a base tensor (synthetic checkpoints only; they are not
+    tensors of the state dict). "decisive": the lm_head rows of the action tokens."""
+    if recipe != "decisive" or d.vocab < TOKENIZER_VOCAB:
+        return []
+    return [TensorSpec("language_model.lm_head.weight#action_rows", (N_ACTION_TOKENS, d.llm_dim), 0.0, 0.12,
+                       base="language_model.lm_head.weight", row0=TOKENIZER_VOCAB - N_ACTION_TOKENS)]
 
 
 # ---- packed device layout --------------------------------------------------------------------------------------
@@ -295,23 +363,30 @@ class VLAWeights:
     lm_head: torch.Tensor      # packed
     placements: Dict[str, Placement] = field(default_factory=dict)
     groups: List[PackedGroup] = field(default_factory=list)
+    passthrough: Dict[str, torch.Tensor] = field(default_factory=dict)   # passthrough_specs(): stored, never executed
 
-    def _specs(self) -> Dict[str, TensorSpec]:
-        return {s.name: s for s in tensor_specs(self.dims)}
+    def _specs(self, recipe: str = "init") -> Dict[str, TensorSpec]:
+        return {s.name: s for s in tensor_specs(self.dims, recipe)}
 
     # ---- filling ----
-    def fill_synthetic(self, seed: int = 0) -> "VLAWeights":
+    def fill_synthetic(self, seed: int = 0, recipe: str = "init") -> "VLAWeights":
         """Fill every tensor on the device with the deterministic generator (bl_fill_synth_bf16_2d), then pack the GEMM
         weights (bl_pack_weight_bf16); the CPU oracle builds the identical tensors from the same (name, seed, mean,
-        std) with oracle/synth.py."""
+        std) with oracle/synth.py. `recipe`: see tensor_specs()."""
         from . import ops
         self.__dict__.pop("_fp8_layers", None)        # derived e4m3 copies (engine.py) follow the bf16 weights
-        specs = self._specs()
+        specs = self._specs(recipe)
+        overlays: Dict[str, List[TensorSpec]] = {}
+        for ov in synthetic_overlays(self.dims, recipe):
+            overlays.setdefault(ov.base, []).append(ov)
 
         def fill(flat, name):
             spec, pl = specs[name], self.placements[name]
             ops.fill_synth(flat[pl.offset:], tensor_seed(name, seed), spec.mean, spec.std / IRWIN_HALL_SD,
                            rows=pl.rows, cols=pl.cols, ld=pl.ld)
+            for ov in overlays.get(name, ()):           # a row block of this tensor, generated on its own
+                ops.fill_synth(flat[pl.offset + ov.row0 * pl.ld:], tensor_seed(ov.name, seed), ov.mean,
+                               ov.std / IRWIN_HALL_SD, rows=ov.shape[0], cols=pl.cols, ld=pl.ld)
         for name, pl in self.placements.items():
             if pl.group is None:
                 fill(pl.dst.view(-1), name)
@@ -320,6 +395,8 @@ class VLAWeights:
             for name in g.members:
                 fill(staging.view(-1), name)
             _pack(staging, g.packed)
+        for sp in passthrough_specs(self.dims):
+            ops.fill_synth(self.passthrough[sp.name].view(-1), tensor_seed(sp.name, seed), sp.mean, sp.std / IRWIN_HALL_SD)
         return self
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> "VLAWeights":
@@ -339,6 +416,11 @@ class VLAWeights:
         for name, pl in self.placements.items():
             if pl.group is None and name in sd:
                 put(pl.dst.view(-1), name)
+        for name, t in self.passthrough.items():      # never-executed tensors: kept for export (optional on input)
+            if name in sd:
+                if tuple(sd[name].shape) != tuple(t.shape):
+                    raise ValueError(f"{name}: expected {tuple(t.shape)}, got {tuple(sd[name].shape)}")
+                t.copy_(sd[name].to(device=t.device, dtype=torch.bfloat16))
         for g in self.groups:
             if not all(n in sd for n in g.members):
                 continue
@@ -359,7 +441,9 @@ class VLAWeights:
             staging = _unpack(g.packed).contiguous()
             for name in g.members:
                 out[name] = _block_view(staging.view(-1), self.placements[name]).clone().reshape(specs[name].shape)
-        return {n: out[n] for n in specs}
+        out = {n: out[n] for n in specs}
+        out.update({n: t.clone() for n, t in self.passthrough.items()})
+        return out
 
 
 def allocate(dims: VLADims, device: torch.device | str = "cuda") -> VLAWeights:
@@ -453,4 +537,7 @@ def allocate(dims: VLADims, device: torch.device | str = "cuda") -> VLAWeights:
     for name, (gi, off, rows, cols, ld) in grouped.items():
         w.placements[name] = Placement(None, off, rows, cols, ld, w.groups[gi])
         w.groups[gi].members.append(name)
+    # never-executed checkpoint tensors (≈ 45 M parameters, 90 MB): plain tensors beside the arena; norm scales start at 1
+    for sp in passthrough_specs(dims):
+        w.passthrough[sp.name] = torch.full(sp.shape, sp.mean, dtype=torch.bfloat16, device=device)
     return w

@@ -50,9 +50,36 @@ def synth_f32(n: int, seed32: int, mean: float, std: float, start: int = 0) -> n
     return np.float32(mean) + s * scale          # two separately rounded fp32 ops (no FMA in numpy)
 
 
-def synth_bf16(shape: Tuple[int, ...], seed32: int, mean: float, std: float) -> torch.Tensor:
+_C = None
+
+
+def _c_lib():
+    """oracle/_ref/libbl_oracle.so (oracle/synth_c.c, built by oracle/Makefile) — the same generator in C for full-size
+    checkpoints; None when it has not been built (the numpy path below is then used: identical bits, ~200x slower)."""
+    global _C
+    if _C is None:
+        import ctypes
+        from pathlib import Path
+        so = Path(__file__).resolve().parent / "_ref" / "libbl_oracle.so"
+        if so.exists():
+            lib = ctypes.CDLL(str(so))
+            lib.bl_oracle_synth_bf16.restype = None
+            lib.bl_oracle_synth_bf16.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float,
+                                                 ctypes.c_float, ctypes.c_int64]
+            _C = lib
+        else:
+            _C = False
+    return _C or None
+
+
+def synth_bf16(shape: Tuple[int, ...], seed32: int, mean: float, std: float, use_c: bool = True) -> torch.Tensor:
     n = int(np.prod(shape))
     out = torch.empty(n, dtype=torch.bfloat16)
+    lib = _c_lib() if use_c and n >= (1 << 16) else None
+    if lib is not None:
+        lib.bl_oracle_synth_bf16(out.data_ptr(), n, seed32 & 0xFFFFFFFF, float(np.float32(mean)),
+                                 float(np.float32(std / IRWIN_HALL_SD)), 0)
+        return out.view(shape)
     step = 1 << 24                                   # bound temporary memory for the 131 M-element embeddings
     for s in range(0, n, step):
         m = min(step, n - s)
@@ -60,6 +87,12 @@ def synth_bf16(shape: Tuple[int, ...], seed32: int, mean: float, std: float) -> 
     return out.view(shape)
 
 
-def synth_state_dict(specs: Iterable, seed: int = 0) -> Dict[str, torch.Tensor]:
-    """specs: objects with .name .shape .mean .std (bridgelang_amd.weights.tensor_specs) → HF-named bf16 CPU tensors."""
-    return {s.name: synth_bf16(tuple(s.shape), tensor_seed(s.name, seed), s.mean, s.std) for s in specs}
+def synth_state_dict(specs: Iterable, seed: int = 0, overlays: Iterable = ()) -> Dict[str, torch.Tensor]:
+    """specs: objects with .name .shape .mean .std (bridgelang_amd.weights.tensor_specs) → HF-named bf16 CPU tensors.
+    overlays (bridgelang_amd.weights.synthetic_overlays): row blocks generated on their own (.name seeds them) and written
+    over rows [.row0, .row0 + .shape[0]) of tensor .base — the same two fills the device generator performs."""
+    sd = {s.name: synth_bf16(tuple(s.shape), tensor_seed(s.name, seed), s.mean, s.std) for s in specs}
+    for ov in overlays:
+        if ov.base in sd:
+            sd[ov.base][ov.row0:ov.row0 + ov.shape[0]] = synth_bf16(tuple(ov.shape), tensor_seed(ov.name, seed), ov.mean, ov.std)
+    return sd

@@ -3,9 +3,15 @@ greedy argmax) vs the CPU oracle on the SAME synthetic checkpoint (bit-identical
 generator), at reduced widths the oracle finishes in seconds. Full-size (7B) behaviour is covered by size-independent
 properties in test_full_size_gpu.py.
 
-Tolerances: logits / activations within 1e-3·scale... is the north-star bar for the bf16 path at the logits; token ids
-must match the oracle wherever the oracle's own decision is not a numerical coin-flip (top-2 gap > 2 bf16 ulps of the
-logit); coin-flip positions are counted and reported, never silently accepted beyond a small budget.
+Bars. Per kernel the HIP path is bit-identical to the oracle on >= 99.9 % of elements (tests/test_ops_gpu.py at small
+sizes, tests/test_per_op_full_size_gpu.py on real 7B activations). END TO END two valid fp32 summation orders already
+disagree at the bf16-ulp level after a few layers, and a randomly initialised network amplifies that (tools/drift_7b.py),
+so the end-to-end bounds below are max |difference| / max |reference| with the value MEASURED on MI355X + ~50 % margin,
+printed by every test: vision features 8e-3 (measured 4.5e-3), projector 8e-3 (4.2e-3), first-token logits 1.2e-2
+(6.5e-3), KV cache 1.2e-2 (6.9e-3 / 8.0e-3 in layers 0 / 1; one bf16 ulp of the largest element is 3.9e-3), later-step
+logits 1.5e-2 (6.1e-3 … 7.9e-3). Token ids must
+match the oracle wherever the oracle's own decision is not a numerical coin-flip (top-2 gap > 2 bf16 ulps of the logit);
+coin-flip positions are counted and reported, never silently accepted beyond a small budget.
 """
 import numpy as np
 import pytest
@@ -17,6 +23,7 @@ from oracle import synth as S
 pytestmark = pytest.mark.gpu
 
 B, L = 3, 12
+FEATS_TOL, PROJ_TOL, LOGITS0_TOL, KCACHE_TOL, LOGITS_TOL = 8e-3, 8e-3, 1.2e-2, 1.2e-2, 1.5e-2     # see the module docstring
 
 
 def make_inputs(dims, batch=B, seq=L, seed=0):
@@ -47,9 +54,11 @@ def setup(dev):
 
 def test_synthetic_checkpoint_bit_identical(setup):
     dims, w, sd, *_ = setup
+    from bridgelang_amd import weights as W
     got = w.state_dict()
-    assert set(got) == set(sd)
-    for name, ref in sd.items():
+    sd_pt = S.synth_state_dict(W.passthrough_specs(dims), seed=7)      # never-executed tensors, stored for export
+    assert set(got) == set(sd) | set(sd_pt)
+    for name, ref in {**sd, **sd_pt}.items():
         assert torch.equal(got[name].cpu().view(torch.int16), ref.view(torch.int16)), name
 
 
@@ -67,11 +76,11 @@ def test_prefill_intermediates_and_logits(setup, dev):
     feats = R.vision_backbone(p, sd, pv.float(), dims.dino.heads, dims.dino.n_run, dims.siglip.heads, dims.siglip.n_run)
     e = rel_err(eng.feats.view(B, 256, -1), feats)
     print(f"\nvision features rel err {e:.3g}")
-    assert e < 2e-2, f"vision features rel err {e}"
+    assert e < FEATS_TOL, f"vision features rel err {e}"
     proj = R.projector(p, sd, feats)
     e = rel_err(eng.x[:, 1:257], proj)
     print(f"projector rel err {e:.3g}")
-    assert e < 2e-2, f"projector rel err {e}"
+    assert e < PROJ_TOL, f"projector rel err {e}"
     eng.generate(ids.to(dev), pv.to(dev))
     torch.cuda.synchronize()
     logits, cache, _ = oracle.prefill(ids, pv)
@@ -80,11 +89,12 @@ def test_prefill_intermediates_and_logits(setup, dev):
     scale = ref_last.abs().max().item()
     err = (got - ref_last).abs().max().item()
     print(f"\nprefill last-row logits: max abs err {err:.4g}, scale {scale:.4g}, rel {err / scale:.3g}")
-    assert err <= 2e-2 * scale, f"logits err {err} vs scale {scale}"
+    assert err <= LOGITS0_TOL * scale, f"logits err {err} vs scale {scale}"
     # KV cache parity for the first and last layer
     for l in (0, dims.llm_layers - 1):
         e = rel_err(eng.k_cache[l][:, :, :eng.S], cache.k[l])
-        assert e < 2e-2, f"k cache layer {l} rel err {e}"
+        print(f"k cache layer {l} rel err {e:.3g}")
+        assert e < KCACHE_TOL, f"k cache layer {l} rel err {e}"
 
 
 def test_greedy_ids_match_oracle(setup, dev):
@@ -107,7 +117,8 @@ def test_greedy_ids_match_oracle(setup, dev):
     for b in range(B):
         if torch.equal(got[b], ref_ids[b]):
             err = (eng.logits[:, b].cpu() - ref_logits[b]).abs().max().item()
-            assert err <= 2e-2 * ref_logits[b].abs().max().item()
+            print(f"sequence {b}: max |dlogit| / scale over the 7 steps {err / ref_logits[b].abs().max().item():.3g}")
+            assert err <= LOGITS_TOL * ref_logits[b].abs().max().item()
 
 
 def test_graph_replay_equals_eager(setup, dev):

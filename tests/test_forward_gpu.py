@@ -52,8 +52,10 @@ def test_forward_logits_loss_and_mask(model, dev):
     scale = ref.abs().max().item()
     err = (got - ref).abs().max().item()
     print(f"\nforward(): all-row logits max err {err:.3g} (scale {scale:.3g})")
-    assert err <= 2e-2 * scale
-    assert ((out.projector_features.float().cpu() - proj_ref).abs().max() <= 2e-2 * proj_ref.abs().max()).item()
+    assert err <= 1.2e-2 * scale        # measured 8.0e-3 of the logit scale (all 270 x 3 rows, padded batch) + margin
+    ep = ((out.projector_features.float().cpu() - proj_ref).abs().max() / proj_ref.abs().max()).item()
+    print(f"projector features rel err {ep:.3g}")
+    assert ep <= 8e-3                   # measured 4e-3 … 5e-3
     # HF loss: shift, ignore -100, mean over valid tokens — computed on the oracle's logits
     full_lab = torch.cat([labels[:, :1], torch.full((B, 256), -100), labels[:, 1:]], 1)
     loss_ref = torch.nn.functional.cross_entropy(logits_ref[:, :-1].reshape(-1, dims.vocab), full_lab[:, 1:].reshape(-1),

@@ -79,7 +79,8 @@ def test_llama_layer_full_width_vs_oracle(full, dev):
     v = R.linear(p, h, sd[f"{lm}.self_attn.v_proj.weight"]).view(2, S, H, hd).transpose(1, 2)
     cos, sin = R.rope_tables(hd, dims.max_pos, dims.rope_theta)
     q, k = R.apply_rope(p, q, cos, sin, 0), R.apply_rope(p, k, cos, sin, 0)
-    assert rel(eng.k_cache[0][sel][:, :, :S], k) < 2e-2
+    ek = rel(eng.k_cache[0][sel][:, :, :S], k)
+    assert ek < 8e-3, ek            # one bf16 ulp of the largest element is 3.9e-3
     a = R.attention(p, q, k, v, hd ** -0.5, True).transpose(1, 2).reshape(2, S, D)
     x1 = p.rb(xs + R.linear(p, a, sd[f"{lm}.self_attn.o_proj.weight"]))
     h2 = R.rmsnorm(p, x1, sd[f"{lm}.post_attention_layernorm.weight"], dims.rms_eps)
@@ -87,8 +88,8 @@ def test_llama_layer_full_width_vs_oracle(full, dev):
                R.linear(p, h2, sd[f"{lm}.mlp.up_proj.weight"]))
     x2 = p.rb(x1 + R.linear(p, act, sd[f"{lm}.mlp.down_proj.weight"]))
     e = rel(eng.x[sel], x2)
-    print(f"\nfull-width Llama layer 0: rel err of the residual stream {e:.3g}")
-    assert e < 2e-2
+    print(f"\nfull-width Llama layer 0: rel err of the residual stream {e:.3g}, of the rotated keys {ek:.3g}")
+    assert e < 1e-2                 # measured 6.6e-3 (7 kernels chained); per-kernel bars: test_per_op_full_size_gpu.py
 
 
 def test_projector_and_vit_block_full_width_vs_oracle(full, dev):
@@ -108,7 +109,7 @@ def test_projector_and_vit_block_full_width_vs_oracle(full, dev):
     torch.cuda.synchronize()
     e = rel(eng.x[[0, B - 1], 1:257], R.projector(p, sd, feats))
     print(f"\nfull-width projector rel err {e:.3g}")
-    assert e < 2e-2
+    assert e < 8e-3                 # measured 5e-3 (3 GEMMs + 2 GELUs chained)
     # first block of each tower, re-run in isolation from a known input
     for ti, (tw, vb) in enumerate(((w.dino, eng.vbuf[0]), (w.siglip, eng.vbuf[1]))):
         t = tw.dims
@@ -138,7 +139,7 @@ def test_projector_and_vit_block_full_width_vs_oracle(full, dev):
         x2 = p.rb(x1 + o)
         e = rel(vb["x"][:M * Dm].view(B, T, Dm)[[0, B - 1]], x2)
         print(f"full-width {t.prefix.split('.')[-1]} block 0 rel err {e:.3g}")
-        assert e < 2e-2
+        assert e < (5e-3 if t.layerscale else 1.6e-2)      # measured 2.5e-3 (DINOv2, LayerScale 0.1) / 1.1e-2 (SigLIP)
 
 
 def test_replay_determinism_and_batch_equivariance(full, dev):
@@ -238,11 +239,22 @@ def test_fp8_prefill_full_size(full, dev):
     del e8
 
 
-def test_kv_cache_consistency_full_size(full, dev):
+@pytest.mark.parametrize("recipe", ["decisive", "init"])
+def test_kv_cache_consistency_full_size(full, dev, recipe):
     """Greedy token t+1 produced by the cached decode must equal the greedy token produced by a fresh prefill over
-    prompt + tokens[0..t] (the reference's use_cache=False path, run_openvla_demo.py:43, gives the same ids)."""
+    prompt + tokens[0..t] (the reference's use_cache=False path, run_openvla_demo.py:43, gives the same ids). The two
+    paths are identical math in different kernels (weight-streaming GEMM / decode attention vs tiled GEMM / prefill
+    attention: other fp32 summation orders), so logits agree to the network's bf16 noise and ids may differ only where
+    the top-2 gap is inside that noise — on the "decisive" checkpoint that leaves most sequences in agreement; on the
+    bench checkpoint ("init": flat logits, chaotic network) the agreement rate is printed, not asserted."""
     from bridgelang_amd.engine import OpenVLAEngine
-    dims, w, eng, ids, pv = full
+    from test_cfg_7b_golden_gpu import _weights
+    dims, w0, eng0, ids, pv = full
+    if recipe == "init":
+        w, eng = w0, eng0
+    else:
+        _, w = _weights(recipe, dev)
+        eng = OpenVLAEngine(w, B, L)
     got = eng.generate(ids, pv).clone()
     for t in (1, 3):
         longer = torch.cat([ids, got[:, :t]], dim=1)
@@ -252,14 +264,12 @@ def test_kv_cache_consistency_full_size(full, dev):
         scale = lg_fresh.abs().max().item()
         dl = (lg_cached - lg_fresh).abs().amax(dim=1)                  # per-sequence logit noise between the two paths
         same = (nxt == got[:, t]).float().mean().item()
-        print(f"\ncached step {t}: {same * 100:.0f}% of sequences agree with the uncached recomputation; "
+        print(f"\n{recipe}: cached step {t}: {same * 100:.0f}% of sequences agree with the uncached recomputation; "
               f"max |dlogit| {dl.max().item():.3g} (scale {scale:.3g})")
-        # identical math, but the last position runs through the weight-streaming GEMM / decode attention instead of the
-        # tiled GEMM / prefill attention (different fp32 summation order): logits agree to bf16 noise, ids may differ
-        # only where the top-2 gap is within that noise
         assert dl.max().item() <= 4e-2 * scale                          # measured 2.8–3.1 % over input realisations
         for bidx in (nxt != got[:, t]).nonzero().flatten().tolist():
             top2 = lg_fresh[bidx].topk(2).values
             assert (top2[0] - top2[1]).item() <= 2 * dl[bidx].item() + 1e-6, f"sequence {bidx}: decisive gap"
-        assert same >= 0.75
+        if recipe == "decisive":
+            assert same >= 0.75
         del e2

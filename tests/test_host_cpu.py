@@ -58,7 +58,7 @@ def test_weight_layout_roundtrip_and_packing():
     sd = {s.name: torch.randn(s.shape, generator=g).to(torch.bfloat16) for s in specs}
     w = W.allocate(dims, "cpu").load_state_dict(sd)
     back = w.state_dict()
-    assert list(back) == [s.name for s in specs]
+    assert list(back) == [s.name for s in specs] + [s.name for s in W.passthrough_specs(dims)]   # executed tensors, then pass-through
     assert all(torch.equal(back[k], sd[k]) for k in sd)
     # fragment-major element map: packed[nt][ks][lane][j] = W[16nt + (lane&15)][32ks + 8(lane>>4) + j]
     ow, pk = sd["language_model.model.layers.0.self_attn.o_proj.weight"], w.layers[0].o_w
@@ -101,6 +101,113 @@ def test_synth_generator_deterministic_and_normalish():
     assert np.array_equal(x, y)
 
 
+def test_synth_c_helper_matches_numpy_generator():
+    """oracle/synth_c.c (built by oracle/Makefile into oracle/_ref/) is the same generator bit for bit."""
+    import subprocess
+    from pathlib import Path
+    from oracle import synth as S
+    root = Path(__file__).resolve().parent.parent
+    subprocess.run(["make", "-C", str(root / "oracle")], check=True, capture_output=True)
+    S._C = None
+    assert S._c_lib() is not None
+    for shape, mean, std in (((4096, 257), 0.0, 0.02), ((70001,), 1.0, 0.02), ((300, 1000), 0.0, 1.0), ((256, 512), 0.0, 0.12)):
+        a, b = S.synth_bf16(shape, 4242, mean, std, use_c=True), S.synth_bf16(shape, 4242, mean, std, use_c=False)
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), shape
+
+
+def test_decisive_recipe_and_overlay_specs():
+    """The second synthetic checkpoint differs from the bench one only in the stated std values, and its lm_head overlay
+    (action-token rows) is applied identically by the oracle's synth_state_dict."""
+    from bridgelang_amd import weights as W
+    from oracle import synth as S
+    d = W.tiny_dims()
+    a, b = W.tensor_specs(d), W.tensor_specs(d, "decisive")
+    assert [x.name for x in a] == [x.name for x in b] and [x.shape for x in a] == [x.shape for x in b]
+    changed = {x.name.split(".")[-2] for x, y in zip(a, b) if x != y}
+    assert changed == {"proj", "fc2", "o_proj", "down_proj", "embed_tokens"}, changed
+    (ov,) = W.synthetic_overlays(d, "decisive")
+    assert ov.base == "language_model.lm_head.weight" and ov.row0 == 31744 and ov.shape == (256, d.llm_dim)
+    assert W.synthetic_overlays(d, "init") == []
+    sd = S.synth_state_dict(b, seed=3, overlays=[ov])
+    lm = sd["language_model.lm_head.weight"].float()
+    assert abs(lm[31744:32000].std().item() - 0.12) < 5e-3 and abs(lm[:31744].std().item() - 0.02) < 1e-3
+    assert abs(lm[32000:].std().item() - 0.02) < 2e-3
+    with pytest.raises(ValueError):
+        W.tensor_specs(d, "nope")
+
+
+def test_full_size_fixtures_are_well_formed():
+    """tests/golden/cfg1_7b_*.npz (oracle/restate.py at openvla-7b, written by tests/golden/make_cfg_7b.py): shapes,
+    id ranges, logits are bf16 values whose argmax is the stored id, gaps are consistent with the stored logits."""
+    from pathlib import Path
+    gold = Path(__file__).resolve().parent / "golden"
+    files = sorted(gold.glob("cfg1_7b_*.npz"))
+    assert len(files) >= 2
+    for f in files:
+        z = np.load(f)
+        B, L, seed, wseed = [int(v) for v in z["meta"]]
+        assert z["ids"].shape == (B, 7) and z["input_ids"].shape == (B, L)
+        assert (z["ids"] >= 0).all() and (z["ids"] < 32064).all()
+        if str(z["recipe"]) == "decisive":
+            assert ((z["ids"] >= 31744) & (z["ids"] < 32000)).all()
+        if "logits_bf16" in z:
+            lg = torch.from_numpy(z["logits_bf16"].astype(np.int16)).view(torch.bfloat16).float()
+            assert lg.shape == (B, 7, 32064) and np.array_equal(lg.argmax(-1).numpy(), z["ids"])
+            t2 = lg.topk(2, dim=-1).values
+            assert np.allclose((t2[..., 0] - t2[..., 1]).numpy(), z["top2_gap"])
+        else:
+            assert np.array_equal(z["topk_idx"][..., 0], z["ids"])
+
+
+def _timm_vit_keys(depth, layerscale, cls_reg, attn_pool):
+    """state_dict keys of a timm 0.9.10 VisionTransformer(num_classes=0) († from knowledge of timm — SURVEY App. A.1;
+    the reference builds the towers at modeling_prismatic.py:78-101 and loads them strictly, prismatic.py:113-116)."""
+    keys = (["cls_token", "reg_token"] if cls_reg else []) + ["pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"]
+    for i in range(depth):
+        for n in ("norm1", "attn.qkv", "attn.proj", "norm2", "mlp.fc1", "mlp.fc2"):
+            keys += [f"blocks.{i}.{n}.weight", f"blocks.{i}.{n}.bias"]
+        if layerscale:
+            keys += [f"blocks.{i}.ls1.gamma", f"blocks.{i}.ls2.gamma"]
+    keys += ["norm.weight", "norm.bias"]
+    if attn_pool:
+        keys += ["attn_pool.latent"] + [f"attn_pool.{n}.{wb}" for n in ("q", "kv", "proj", "norm", "mlp.fc1", "mlp.fc2")
+                                        for wb in ("weight", "bias")]
+    return set(keys)
+
+
+def test_exported_checkpoint_has_every_key_the_reference_loads_strictly():
+    """A state dict written by this package must carry the never-executed tensors too (last ViT block, final norm,
+    SigLIP attention pool): the reference's load is strict. Checked in both layouts, with shapes, at 7B
+    dims on a meta-free CPU layout object of the tiny dims and by spec at 7B."""
+    from bridgelang_amd import weights as W
+    from bridgelang_amd.training import checkpoint as C
+    d = W.tiny_dims()
+    w = W.allocate(d, "cpu")
+    sd = w.state_dict()
+    mods = C.to_model_state_dicts(sd, ("vision_backbone", "projector", "llm_backbone"))
+    vb = mods["vision_backbone"]
+    dino = {k[len("dino_featurizer."):] for k in vb if k.startswith("dino_featurizer.")}
+    sig = {k[len("siglip_featurizer."):] for k in vb if k.startswith("siglip_featurizer.")}
+    assert dino == _timm_vit_keys(d.dino.depth, True, True, False), dino ^ _timm_vit_keys(d.dino.depth, True, True, False)
+    assert sig == _timm_vit_keys(d.siglip.depth, False, False, True), sig ^ _timm_vit_keys(d.siglip.depth, False, False, True)
+    assert set(mods["projector"]) == {f"projector.{i}.{wb}" for i in (0, 2, 4) for wb in ("weight", "bias")}
+    # round trip: load → state_dict keeps the pass-through tensors' values
+    sd2 = {k: torch.randn(v.shape).to(torch.bfloat16) for k, v in sd.items()}
+    w.load_state_dict(sd2)
+    back = w.state_dict()
+    for k in ("vision_backbone.fused_featurizer.attn_pool.kv.weight", f"vision_backbone.featurizer.blocks.{d.dino.depth - 1}.ls2.scale_factor",
+              "vision_backbone.featurizer.norm.bias", f"vision_backbone.fused_featurizer.blocks.{d.siglip.depth - 1}.mlp.fc1.weight"):
+        assert torch.equal(back[k], sd2[k]), k
+    # 7B: the full key set has the public parameter count of openvla-7b (7.54 B)
+    d7 = W.openvla_7b_dims()
+    n = sum(int(np.prod(sp.shape)) for sp in W.tensor_specs(d7) + W.passthrough_specs(d7))
+    assert abs(n - 7.5412e9) < 1e6, n
+    shapes = {sp.name: sp.shape for sp in W.passthrough_specs(d7)}
+    assert shapes["vision_backbone.fused_featurizer.attn_pool.kv.weight"] == (2304, 1152)
+    assert shapes["vision_backbone.fused_featurizer.blocks.26.mlp.fc1.weight"] == (4304, 1152)
+    assert shapes["vision_backbone.featurizer.blocks.23.attn.qkv.weight"] == (3072, 1024)
+
+
 def test_shard_properties():
     from bridgelang_amd.replicas import shard
     for n in (0, 1, 16, 17, 100):
@@ -136,6 +243,32 @@ def test_replicas_gloo_world2(tmp_path):
     lines = sorted(l for o in outs for l in o.splitlines() if l.startswith("RESULT"))
     assert lines[0] == "RESULT 0 2 2.0 0 8 [9, 108]", lines
     assert lines[1] == "RESULT 1 2 2.0 9 16 [9, 108]", lines
+
+
+def test_bench_launcher_starts_one_rank_per_gpu(tmp_path):
+    """`python bench.py --gpus 2` (no torchrun): the parent starts 2 ranks that rendezvous on 127.0.0.1, time exactly K
+    steps between fences, take the max over ranks, and rank 0 prints ONE JSON line with n_gpus = 2 (dry run: gloo, no
+    GPU). The same command under torchrun must accept the ranks it is given, and a --gpus / WORLD_SIZE mismatch is an error."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["ms_per_step"] >= 19.0                      # rank 1 sleeps 20 ms per step: the MAX over ranks is reported
+    assert abs(d["value"] - 2 * 16 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-2 * d["value"]
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29577", str(ROOT / "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 2
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="3", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
 
 
 def test_registries_and_checkpoint_naming():
