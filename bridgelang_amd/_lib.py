@@ -77,6 +77,7 @@ SIGNATURES = {
     "bl_attention_backward_bf16": (C.c_int, [C.POINTER(AttnDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bl_attention_decode_bf16": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "bl_attention_decode_rope_bf16": (C.c_int, [C.POINTER(AttnDesc), _vp, _vp, _i32, _vp]),
+    "bl_attention_decode_rope_pos_bf16": (C.c_int, [C.POINTER(AttnDesc), _vp, _vp, _i32, _vp, _vp]),
     "bl_attention_decode_rope_grouped_bf16": (C.c_int, [C.POINTER(AttnDesc), _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "bl_rope_kvcache_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "bl_embed_splice_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),

@@ -27,6 +27,7 @@ struct AttnArgs {
   float scale_log2e;
   float* lse;      // optional [B*H, lse_rs] base-2 log-sum-exp of the scaled scores (training forward); +inf for empty rows
   int lse_rs;
+  const int* rope_pos;   // decode kernel, optional [B]: per-sequence RoPE position (right-padded prompts); NULL = the cache row
   // fused RoPE + KV-cache write (whole-sequence kernel, head_dim 128): q / k are rotated while they are loaded, the rotated
   // k and v rows are also written to the caches [B, H, cache_len, 128] at positions pos0 + key
   const uint16_t* cos_tab; const uint16_t* sin_tab; uint16_t* k_cache; uint16_t* v_cache; int cache_len, pos0;
@@ -476,8 +477,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p, const uint
   float knv[8], vnv[8];   // ROPE: rotated new key / new value chunk (bf16 values)
   if constexpr (ROPE) {
     // half-split rotation: chunk dc pairs with chunk dc ^ 8; out = bf16(bf16(own*cos) + bf16(±partner*sin))
-    const u32x4_t cq = *(const u32x4_t*)(cos_tab + (long)pos * 64 + (dc & 7) * 8);
-    const u32x4_t sq = *(const u32x4_t*)(sin_tab + (long)pos * 64 + (dc & 7) * 8);
+    const int rp = p.rope_pos ? p.rope_pos[b] : pos;   // rotation angle index; the cache row stays `pos`
+    const u32x4_t cq = *(const u32x4_t*)(cos_tab + (long)rp * 64 + (dc & 7) * 8);
+    const u32x4_t sq = *(const u32x4_t*)(sin_tab + (long)rp * 64 + (dc & 7) * 8);
     const float sgn = dc < 8 ? -1.f : 1.f;
     const u32x4_t q_own = *(const u32x4_t*)(p.q + qoff + dc * 8), q_par = *(const u32x4_t*)(p.q + qoff + (dc ^ 8) * 8);
     const u32x4_t k_own = *(const u32x4_t*)(kn + qoff + dc * 8), k_par = *(const u32x4_t*)(kn + qoff + (dc ^ 8) * 8);
@@ -596,6 +598,7 @@ int fill_args(const bl_attn_desc* d, AttnArgs& a) {
   a.B = d->B; a.H = d->H; a.Sq = d->Sq; a.Skv = d->Skv;
   a.scale_log2e = d->scale * 1.44269504088896340736f;
   a.lse = nullptr; a.lse_rs = 0;
+  a.rope_pos = nullptr;
   a.cos_tab = a.sin_tab = nullptr; a.k_cache = a.v_cache = nullptr; a.cache_len = a.pos0 = 0;
   return BL_OK;
 }
@@ -707,6 +710,22 @@ extern "C" int bl_attention_decode_rope_bf16(const bl_attn_desc* d, const bl_bf1
   if (d->head_dim != 128 || d->Sq != 1 || d->Skv > 2048 || pos < 0 || d->Skv != pos + 1) return BL_E_SHAPE;
   if ((((uintptr_t)d->o) & 15) || !bl_aligned16(cos_tab) || !bl_aligned16(sin_tab)) return BL_E_ALIGN;
   const long D = (long)d->H * d->head_dim;   // q / k_new / v_new are the three thirds of the fused qkv row
+  hipLaunchKernelGGL((attn_decode_kernel<true>), dim3(d->B * d->H), dim3(256), 0, (hipStream_t)stream, a, d->q + D,
+                     d->q + 2 * D, cos_tab, sin_tab, pos, DecodeGroups{});
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_attention_decode_rope_pos_bf16(const bl_attn_desc* d, const bl_bf16* cos_tab, const bl_bf16* sin_tab,
+                                                 int32_t pos, const int32_t* rope_pos, void* stream) {
+  AttnArgs a;
+  const int rc = fill_args(d, a);
+  if (rc != BL_OK) return rc;
+  if (!cos_tab || !sin_tab || !rope_pos) return BL_E_ARG;
+  if (d->head_dim != 128 || d->Sq != 1 || d->Skv > 2048 || pos < 0 || d->Skv != pos + 1) return BL_E_SHAPE;
+  if ((((uintptr_t)d->o) & 15) || !bl_aligned16(cos_tab) || !bl_aligned16(sin_tab)) return BL_E_ALIGN;
+  a.rope_pos = rope_pos;
+  const long D = (long)d->H * d->head_dim;
   hipLaunchKernelGGL((attn_decode_kernel<true>), dim3(d->B * d->H), dim3(256), 0, (hipStream_t)stream, a, d->q + D,
                      d->q + 2 * D, cos_tab, sin_tab, pos, DecodeGroups{});
   BL_CHECK_LAUNCH();

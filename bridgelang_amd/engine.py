@@ -41,7 +41,7 @@ def _fp8_layers(weights: VLAWeights) -> list:
 
 class OpenVLAEngine:
     def __init__(self, weights: VLAWeights, batch: int, prompt_len: int, n_new: int = 7, all_rows: bool = False,
-                 use_mask: bool = False, splitk: bool = False, fp8: bool = False):
+                 use_mask: bool = False, splitk: bool = False, fp8: bool = False, padded: bool = False):
         """all_rows=True builds the training/eval-style forward instead of generation: logits for every position
         (`logits_all` [B*S, vocab] fp32) and no decode steps. use_mask=True threads a [B, S] uint8 key-padding mask
         (`key_mask`, 1 = attend) through the Llama attention (modeling_prismatic.py:387-390). splitk=True lets
@@ -50,8 +50,16 @@ class OpenVLAEngine:
         on its batch slot (it breaks "batch-B ≡ B × batch-1 bit for bit", tests/test_full_size_gpu.py). fp8=True runs the
         Llama prefill projections (qkv, o, gate/up, down of every layer but the last) as W8A8 e4m3 GEMMs on the
         block-scaled MFMA (BASELINE configs[4]; per-token × per-channel scales, ops.gemm_fp8) — an extension with no
-        reference counterpart: results agree with the bf16 path to quantisation noise, not bit for bit."""
+        reference counterpart: results agree with the bf16 path to quantisation noise, not bit for bit. padded=True builds
+        the generation plan for a batch of RIGHT-PADDED prompts (`set_padded_inputs`; HF generation with an attention
+        mask, modeling_prismatic.py:387-390): pad positions are hidden from every attention, each sequence's first token
+        comes from ITS last real position, and the new tokens are rotated at the sequence's own position — every
+        sequence gets exactly the ids and logits it gets alone, un-padded (tests/test_hf_boundary_gpu.py)."""
         self.w, self.dims = weights, weights.dims
+        self.padded = padded
+        use_mask = use_mask or padded
+        if padded and (all_rows or fp8):
+            raise ValueError("padded generation is built for the bf16 generation plan")
         d = self.dims
         if all_rows:
             n_new = 1
@@ -91,7 +99,17 @@ class OpenVLAEngine:
         self.qkvd, self.actd = z(B, 3 * D), z(B, I)
         self.cos, self.sin = rope_tables(d.head_dim, d.max_pos, d.rope_theta, dev)
         self.ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev) if splitk else None   # split-K scratch (opt-in)
-        self.key_mask = torch.ones(B, S, dtype=torch.uint8, device=dev) if use_mask else None
+        if padded:        # one mask over the whole cache: real prompt rows and every generated row are visible
+            if d.head_dim != 128 or not ops.skinny_supported(B, D, EPI_NONE):
+                raise NotImplementedError("padded generation needs head_dim 128 and a batch of at most 16")
+            self.cache_mask = torch.ones(B, self.cache_len, dtype=torch.uint8, device=dev)
+            self.key_mask = self.cache_mask[:, :S]
+            self.last_row = torch.full((B,), S - 1, dtype=torch.int64, device=dev)      # index of the last real position
+            self.rope_pos = torch.zeros(n_new, B, dtype=torch.int32, device=dev)        # rotation position of new token t
+            self.q_last, self.x_last = z(B, 3 * D), z(B, D)
+            self._rows = torch.arange(B, device=dev)
+        else:
+            self.key_mask = torch.ones(B, S, dtype=torch.uint8, device=dev) if use_mask else None
         self.logits_all = z(B * S, d.vocab, dtype=torch.float32) if all_rows else None
         self.fp8 = fp8
         if fp8:
@@ -206,12 +224,24 @@ class OpenVLAEngine:
                 plan.append(self._g(act, lw.down_w, x, EPI_RES, res=x, run=False))
                 continue
             plan.append(ops.rope_kvcache(qkv, self.cos, self.sin, kc, vc, B=B, S=S, H=H, head_dim=hd, pos0=0, run=False))
-            if last:
+            if last and self.padded:
+                # each sequence's last REAL position: gather its (rotated) q row and residual row (index glue, no
+                # arithmetic), then the same single-query attention / weight-streaming GEMMs as the un-padded plan
+                def gather(qkv=qkv, x3=x3):
+                    self.q_last.copy_(qkv.view(B, S, 3 * D)[self._rows, self.last_row])
+                    self.x_last.copy_(x3[self._rows, self.last_row])
+                plan.append(ops.glue("gather_last_real_rows", gather, (qkv, x3)))
+                q_last, x_last = self.q_last, self.x_last
+                plan.append(ops.attention_decode(q_last, kc, vc, aod, B=B, H=H, Skv=S, head_dim=hd,
+                                                 q_strides=(3 * D, hd, 3 * D), k_strides=cs, v_strides=cs,
+                                                 o_strides=(D, hd, D), key_mask=self.cache_mask, run=False))
+            elif last:
                 q_last = qkv.view(B, S, 3 * D)[:, S - 1]                       # roped in place; row stride S·3D
                 x_last = x3[:, S - 1, :]
                 plan.append(ops.attention_decode(q_last, kc, vc, aod, B=B, H=H, Skv=S, head_dim=hd,
                                                  q_strides=(S * 3 * D, hd, 3 * D), k_strides=cs, v_strides=cs,
                                                  o_strides=(D, hd, D), run=False))
+            if last:
                 plan.append(self._g(aod, lw.o_w, xd, EPI_RES, res=x_last, run=False))
                 if ops.skinny_supported(B, D, EPI_SWIGLU):
                     plan.append(self._g(xd, lw.gu_w, actd, EPI_SWIGLU, a_norm=(lw.ln2, d.rms_eps), run=False))
@@ -261,8 +291,9 @@ class OpenVLAEngine:
         for l, lw in enumerate(w.layers):
             if fused:
                 plan.append(self._g(self.xd, lw.qkv_w, self.qkvd, EPI_NONE, a_norm=(lw.ln1, d.rms_eps), run=False))
+                pad_kw = dict(key_mask=self.cache_mask, rope_pos=self.rope_pos[t]) if self.padded else {}
                 plan.append(ops.attention_decode_rope(self.qkvd, self.k_cache[l], self.v_cache[l], self.aod, self.cos,
-                                                      self.sin, B=B, H=H, head_dim=hd, pos=pos, run=False))
+                                                      self.sin, B=B, H=H, head_dim=hd, pos=pos, run=False, **pad_kw))
             else:
                 plan.append(ops.rmsnorm(self.xd, lw.ln1, self.hd, d.rms_eps, run=False))
                 plan.append(self._g(self.hd, lw.qkv_w, self.qkvd, EPI_NONE, run=False))
@@ -333,6 +364,24 @@ class OpenVLAEngine:
             raise ValueError(f"pixel_values must be [{self.B}, 6, 224, 224]")
         self.input_ids.copy_(input_ids)
         self.pixel_values.copy_(pixel_values.to(torch.bfloat16))
+
+    def set_padded_inputs(self, input_ids: torch.Tensor, pixel_values: torch.Tensor, attention_mask: torch.Tensor) -> None:
+        """Right-padded prompts [B, L] with attention_mask [B, L] (1 = real token; the collator's layout,
+        util/data_utils.py:101-142). Fills the cache mask, the per-sequence last position and rotation positions."""
+        if not self.padded:
+            raise ValueError("engine was not built with padded=True")
+        m = attention_mask.to(self.device).bool()
+        if tuple(m.shape) != (self.B, self.L):
+            raise ValueError(f"attention_mask must be {(self.B, self.L)}")
+        n_real = m.sum(dim=1)
+        if bool((n_real < 1).any()) or not bool((m == (torch.arange(self.L, device=self.device)[None, :] < n_real[:, None])).all()):
+            raise ValueError("generate(): prompts must be right-padded (attention_mask = 1…1 0…0) with at least one token")
+        self.set_inputs(input_ids, pixel_values)
+        P = self.dims.n_patches
+        self.cache_mask.fill_(1)
+        self.cache_mask[:, 1 + P:self.S] = m[:, 1:].to(torch.uint8)          # column 0 (BOS) and the 256 patch columns stay on
+        self.last_row.copy_(P + n_real - 1)
+        self.rope_pos.copy_((P + n_real)[None, :].to(torch.int32) + torch.arange(self.n_new, device=self.device, dtype=torch.int32)[:, None] - 1)
 
     @torch.no_grad()
     def generate(self, input_ids: torch.Tensor, pixel_values: torch.Tensor) -> torch.Tensor:

@@ -7,19 +7,33 @@ Drop-in for prismatic/extern/hf/modeling_prismatic.py: same class names, `forwar
 finetune.py:219,270). What sits behind it is not timm/transformers/flash-attn but bridgelang_amd.engine (hand-written
 gfx950 kernels); there is no eager/PyTorch fallback, so constructing the model without a GPU + built library raises.
 
+The classes are real `transformers.PreTrainedModel` subclasses, so the reference's callers load them the way they load
+the reference (`AutoConfig.register` / `AutoModelForVision2Seq.register` + `from_pretrained(local_dir, torch_dtype=
+torch.bfloat16, low_cpu_mem_usage=True, trust_remote_code=True)`, finetune.py:151-166, deploy.py:66-75,
+run_openvla_demo.py:21-28 — `register_auto_classes()` below; transformers >= 5 renamed the Auto class to
+`AutoModelForImageTextToText`, both are served). `from_pretrained` reads the safetensors shards straight into the packed
+weight arena on the GPU (no nn.Parameter copies of the 15 GB checkpoint); `.to()` / `.eval()` / `.device` / `.dtype`
+behave as on any HF model as long as the target is the GPU the weights already live on and bf16. The model owns no
+nn.Parameters (the weights are the arena), so autograd-based wrappers (PEFT, DDP) have nothing to hook: training goes
+through bridgelang_amd.training (scripts/finetune.py, scripts/train.py keep the reference scripts' flags).
+
 Differences from the reference, all deliberate:
   * batched `predict_action` is supported (returns [B, 7]); batch 1 returns the reference's 1-D array.
+  * batched generation takes RIGHT-padded prompts + attention_mask (the collator's layout); every sequence gets the ids
+    it gets alone (the reference asserts batch 1 in its cached branch, :326, :460-463).
   * the greedy loop runs on-device (no per-token host sync); `do_sample=True` is rejected.
   * when 29871 is appended to the prompt the attention mask is extended with it (reference quirk C.1).
 """
 from __future__ import annotations
 
+from collections import OrderedDict
 from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Any, Dict, Optional, Tuple, Union
 
 import numpy as np
 import torch
+from transformers import PreTrainedModel
 
 from ...engine import OpenVLAEngine
 from ...weights import TowerDims, VLADims, VLAWeights, allocate
@@ -64,50 +78,134 @@ class PrismaticCausalLMOutputWithPast:
                                  self.projector_features) if v is not None)
 
 
-class PrismaticForConditionalGeneration:
+class PrismaticPreTrainedModel(PreTrainedModel):
+    """modeling_prismatic.py:176-213: the HF base class of the reference's models (config class, support flags)."""
     config_class = PrismaticConfig
+    base_model_prefix = "model"
+    supports_gradient_checkpointing = False
+    _no_split_modules = ["PrismaticProjector"]
+    _skip_keys_device_placement = "past_key_values"
+    _supports_flash_attn_2 = True      # attention is this package's own kernel: every attn_implementation request is
+    _supports_flash_attn = True        # accepted and means the same thing
+    _supports_sdpa = True
+    _supports_attention_backend = True
 
-    def __init__(self, config: PrismaticConfig, device: Union[str, torch.device] = "cuda:0",
+    def _init_weights(self, module) -> None:   # weights come from a checkpoint or init_synthetic(); nothing to initialise
+        return
+
+
+class PrismaticForConditionalGeneration(PrismaticPreTrainedModel):
+    config_class = PrismaticConfig
+    _ENGINE_CACHE = 8          # captured engines kept per model (LRU): each holds KV caches + activations + a HIP graph
+
+    def __init__(self, config: PrismaticConfig, device: Union[str, torch.device, None] = None,
                  dims: Optional[VLADims] = None) -> None:
+        super().__init__(config)
         if config.use_fused_vision_backbone is None:
             raise ValueError("Missing config field `use_fused_vision_backbone`")
-        self.config = config
-        self.device = torch.device(device)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self._device = torch.device(device)
         self.dims = dims if dims is not None else dims_from_config(config)
-        self.weights: VLAWeights = allocate(self.dims, self.device)
+        self.weights: VLAWeights = allocate(self.dims, self._device)
         self.vocab_size = self.dims.vocab
         self.pad_token_id = config.pad_token_id
-        self.training = False
-        self._engines: Dict[Tuple[int, int], OpenVLAEngine] = {}
+        self._engines: "OrderedDict[tuple, OpenVLAEngine]" = OrderedDict()
+        self._forward_engines: "OrderedDict[tuple, OpenVLAEngine]" = OrderedDict()
         # attribute path read by finetune.py:270
         self.vision_backbone = SimpleNamespace(
             featurizer=SimpleNamespace(patch_embed=SimpleNamespace(num_patches=self.dims.n_patches)),
             embed_dim=self.dims.vision_dim)
+        self.post_init()
 
-    # ---- weights ----
-    def init_synthetic(self, seed: int = 0) -> "PrismaticForConditionalGeneration":
-        self.weights.fill_synthetic(seed)
+    # ---- HF plumbing over the arena ----
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return torch.bfloat16
+
+    def to(self, *args, **kwargs):
+        """nn.Module.to for a model whose weights are a packed bf16 arena on one GPU: a no-op for the device / dtype it
+        already has (what `from_pretrained(...).to("cuda:0")` asks for), an error otherwise — load with `device=` instead."""
+        device, dtype, _, _ = torch._C._nn._parse_to(*args, **kwargs)
+        if dtype is not None and dtype != torch.bfloat16:
+            raise NotImplementedError(f"the MI355X path computes in bfloat16; .to({dtype}) is not available")
+        if device is not None:
+            want = torch.device(device)
+            if want.type == "cuda" and want.index is None:
+                want = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+            if want != self._device:
+                raise NotImplementedError(f"weights live on {self._device}; pass device={want!s} to from_pretrained() / the "
+                                          f"constructor instead of moving the arena")
         return self
 
-    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", device) if isinstance(device, int) else (device or "cuda"))
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("this class is the inference surface; training runs through bridgelang_amd.training "
+                                      "(scripts/train.py, scripts/finetune.py)")
+        return super().train(False)
+
+    # ---- weights ----
+    def init_synthetic(self, seed: int = 0, recipe: str = "init") -> "PrismaticForConditionalGeneration":
+        self.weights.fill_synthetic(seed, recipe)
+        return self
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True, assign: bool = False):
         self.weights.load_state_dict(state_dict, strict=strict)
         return self
 
-    def state_dict(self) -> Dict[str, torch.Tensor]:
+    def state_dict(self, *args, **kwargs) -> Dict[str, torch.Tensor]:
+        """HF-named tensors (unpacked copies), incl. the never-executed ones the reference loads strictly."""
         return self.weights.state_dict()
 
-    def eval(self):
-        self.training = False
-        return self
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, config: Optional[PrismaticConfig] = None,
+                        device: Union[str, torch.device, None] = None, device_map: Any = None,
+                        dims: Optional[VLADims] = None, torch_dtype: Any = None, dtype: Any = None, **kwargs: Any):
+        """LOCAL HF export (`config.json` + `*.safetensors` [+ index], convert_openvla_weights_to_hf.py:235-249) →
+        model on the GPU. Shards are streamed one at a time straight into the packed arena; nothing is fetched from the
+        hub; files are read with safetensors / json only. Accepted and ignored for call-site compatibility:
+        `trust_remote_code`, `low_cpu_mem_usage`, `attn_implementation`, `quantization_config=None`, …"""
+        from ...models.load import load_hf_directory
+        for k in (torch_dtype, dtype):
+            if k not in (None, torch.bfloat16, "bfloat16", "auto"):
+                raise NotImplementedError(f"only torch_dtype=torch.bfloat16 is available on the MI355X path (got {k})")
+        if kwargs.get("quantization_config") is not None:
+            raise NotImplementedError("bitsandbytes quantisation is a CUDA path; not available here")
+        if device is None and isinstance(device_map, (str, int, torch.device)) and device_map not in ("auto", "balanced"):
+            device = device_map
+        return load_hf_directory(cls, pretrained_model_name_or_path, config=config, device=device, dims=dims)
 
-    def to(self, *args, **kwargs):   # weights live where they were allocated; kept for call-site compatibility
-        return self
+    def save_pretrained(self, save_directory, *args, max_shard_size: Union[int, str] = 5 << 30, **kwargs) -> None:
+        """`config.json` + sharded safetensors under HF names (reference callers: finetune.py:322-337)."""
+        from ...models.load import save_pretrained as _save
+        if isinstance(max_shard_size, str):
+            num, unit = float(max_shard_size[:-2]), max_shard_size[-2:].upper()
+            max_shard_size = int(num * {"KB": 1 << 10, "MB": 1 << 20, "GB": 1 << 30}[unit])
+        _save(self, save_directory, max_shard_bytes=int(max_shard_size))
 
-    def engine(self, batch: int, prompt_len: int) -> OpenVLAEngine:
-        key = (batch, prompt_len, bool(getattr(self, "fp8", False)))
-        if key not in self._engines:      # `model.fp8 = True`: W8A8 e4m3 Llama prefill projections (extension, engine.py)
-            self._engines[key] = OpenVLAEngine(self.weights, batch, prompt_len, fp8=key[2])
-        return self._engines[key]
+    def _lru(self, cache: "OrderedDict", key: tuple, build):
+        """Engines are heavy (KV caches, activations, a captured graph): keep the most recently used few per model and
+        drop the rest, so a server seeing many (batch, prompt length) pairs cannot run HBM dry."""
+        eng = cache.get(key)
+        if eng is None:
+            eng = cache[key] = build()
+            while len(cache) > self._ENGINE_CACHE:
+                cache.popitem(last=False)
+        else:
+            cache.move_to_end(key)
+        return eng
+
+    def engine(self, batch: int, prompt_len: int, n_new: int = 7, padded: bool = False) -> OpenVLAEngine:
+        fp8 = bool(getattr(self, "fp8", False))       # `model.fp8 = True`: W8A8 e4m3 Llama prefill projections (extension)
+        return self._lru(self._engines, (batch, prompt_len, n_new, fp8, padded),
+                         lambda: OpenVLAEngine(self.weights, batch, prompt_len, n_new=n_new, fp8=fp8 and not padded, padded=padded))
 
     # ---- forward (multimodal prefill; logits for all positions) ----
     @torch.no_grad()
@@ -136,7 +234,7 @@ class PrismaticForConditionalGeneration:
             return out.to_tuple()
         return out
 
-    __call__ = forward
+    # nn.Module.__call__ dispatches to forward()
 
     # ---- greedy generation ----
     @torch.no_grad()
@@ -145,26 +243,28 @@ class PrismaticForConditionalGeneration:
                  **_: Any) -> torch.LongTensor:
         """Greedy decoding, returns [B, L + max_new_tokens] like GenerationMixin (prompt ‖ new tokens). `use_cache` is
         accepted and ignored: the KV cache is always used (use_cache=False in the fork's demo re-runs the vision towers
-        7 times, run_openvla_demo.py:43 — same result, 7× the work)."""
+        7 times, run_openvla_demo.py:43 — same result, 7× the work). A batch whose attention_mask has zeros is taken as
+        RIGHT-padded prompts: pads are hidden from attention and every sequence continues from its own last token."""
         if do_sample:
             raise NotImplementedError("only greedy decoding (do_sample=False) is on the HIP path")
         if pixel_values is None:
             raise ValueError("generate() needs pixel_values")
-        if attention_mask is not None and not bool(attention_mask.bool().all()):
-            raise NotImplementedError("padded prompts are not supported in generate(); batch equal-length prompts")
         B, L = input_ids.shape
-        if max_new_tokens != 7:
-            eng = OpenVLAEngine(self.weights, B, L, n_new=max_new_tokens)
+        ids, pv = input_ids.to(self.device), pixel_values.to(self.device)
+        if attention_mask is not None and not bool(attention_mask.bool().all()):
+            eng = self.engine(B, L, max_new_tokens, padded=True)
+            eng.set_padded_inputs(ids, pv, attention_mask)
+            eng.run_eager()
+            new = eng.gen_ids.t()
         else:
-            eng = self.engine(B, L)
-        new = eng.generate(input_ids.to(self.device), pixel_values.to(self.device))
-        return torch.cat([input_ids.to(self.device), new], dim=1)
+            new = self.engine(B, L, max_new_tokens).generate(ids, pv)
+        return torch.cat([ids, new], dim=1)
 
 
 class OpenVLAForActionPrediction(PrismaticForConditionalGeneration):
     config_class = OpenVLAConfig
 
-    def __init__(self, config: OpenVLAConfig, device: Union[str, torch.device] = "cuda:0",
+    def __init__(self, config: OpenVLAConfig, device: Union[str, torch.device, None] = None,
                  dims: Optional[VLADims] = None) -> None:
         super().__init__(config, device, dims)
         self.norm_stats = config.norm_stats
@@ -218,3 +318,25 @@ class OpenVLAForActionPrediction(PrismaticForConditionalGeneration):
 
     def get_action_stats(self, unnorm_key: Optional[str] = None) -> Dict[str, Any]:
         return self.norm_stats[self._check_unnorm_key(self.norm_stats, unnorm_key)]["action"]
+
+
+def register_auto_classes() -> None:
+    """What finetune.py:151-154 / deploy.py:66-69 do before `from_pretrained`: make `model_type == "openvla"` resolve to
+    these classes through the HF Auto classes. transformers < 5 has `AutoModelForVision2Seq`; >= 5 renamed it to
+    `AutoModelForImageTextToText` — whichever exist are registered. Idempotent."""
+    import transformers
+    from transformers import AutoConfig
+    for model_type, cfg in (("prismatic", PrismaticConfig), ("openvla", OpenVLAConfig)):
+        try:
+            AutoConfig.register(model_type, cfg)
+        except ValueError:
+            pass                                     # already registered
+    for name in ("AutoModelForVision2Seq", "AutoModelForImageTextToText"):
+        auto = getattr(transformers, name, None)
+        if auto is None:
+            continue
+        for cfg, cls in ((PrismaticConfig, PrismaticForConditionalGeneration), (OpenVLAConfig, OpenVLAForActionPrediction)):
+            try:
+                auto.register(cfg, cls)
+            except ValueError:
+                pass

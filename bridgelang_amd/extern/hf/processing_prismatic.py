@@ -67,6 +67,32 @@ class PrismaticImageProcessor:
         ops.preprocess_u8(frames, self._mean_std, out)
         return out
 
+    # ---- preprocessor_config.json (the file AutoImageProcessor reads; reference ImageProcessingMixin fields :62-126) ----
+    def to_dict(self) -> Dict[str, Any]:
+        return {"image_processor_type": "PrismaticImageProcessor", "processor_class": "PrismaticProcessor",
+                "use_fused_vision_backbone": self.use_fused_vision_backbone, "image_resize_strategy": self.image_resize_strategy,
+                "input_sizes": [list(s) for s in self.input_sizes], "means": [list(m) for m in self.means],
+                "stds": [list(s) for s in self.stds]}
+
+    def save_pretrained(self, save_directory, **_: Any) -> None:
+        import json
+        from pathlib import Path
+        Path(save_directory).mkdir(parents=True, exist_ok=True)
+        (Path(save_directory) / "preprocessor_config.json").write_text(json.dumps(self.to_dict(), indent=2))
+
+    @classmethod
+    def from_pretrained(cls, path, **_: Any) -> "PrismaticImageProcessor":
+        import json
+        from pathlib import Path
+        f = Path(path) / "preprocessor_config.json"
+        if not f.exists():
+            return cls()
+        raw = json.loads(f.read_text())
+        sizes = raw.get("input_sizes")
+        return cls(use_fused_vision_backbone=raw.get("use_fused_vision_backbone", True),
+                   image_resize_strategy=raw.get("image_resize_strategy", "resize-naive"),
+                   input_sizes=[tuple(s) for s in sizes] if sizes else None, means=raw.get("means"), stds=raw.get("stds"))
+
     def preprocess(self, images: Union[Image.Image, List[Image.Image]], return_tensors: Optional[str] = None,
                    **_: Any) -> Dict[str, Any]:
         if not isinstance(images, list):
@@ -96,6 +122,21 @@ class PrismaticProcessor:
     def __init__(self, image_processor: Optional[PrismaticImageProcessor] = None, tokenizer: Any = None) -> None:
         self.image_processor = image_processor if image_processor is not None else PrismaticImageProcessor()
         self.tokenizer = tokenizer
+
+    @classmethod
+    def from_pretrained(cls, path, **_: Any) -> "PrismaticProcessor":
+        """`AutoProcessor.from_pretrained(local_dir, trust_remote_code=True)` of the reference's callers
+        (run_openvla_demo.py:21, finetune.py:157): image-processor settings from preprocessor_config.json, the tokenizer
+        from the directory's tokenizer files (or the synthetic stand-in when the directory was written without one)."""
+        from ...util.synthetic_tokenizer import load_tokenizer
+        from pathlib import Path
+        has_tok = any((Path(path) / n).exists() for n in ("tokenizer.json", "tokenizer.model"))
+        return cls(PrismaticImageProcessor.from_pretrained(path), load_tokenizer(path if has_tok else "synthetic"))
+
+    def save_pretrained(self, save_directory, **_: Any) -> None:
+        self.image_processor.save_pretrained(save_directory)
+        if self.tokenizer is not None and hasattr(self.tokenizer, "save_pretrained"):
+            self.tokenizer.save_pretrained(save_directory)
 
     def __call__(self, text: Union[str, List[str]], images: Union[Image.Image, List[Image.Image]],
                  return_tensors: str = "pt", **tok_kwargs: Any) -> ProcessorOutput:

@@ -15,7 +15,6 @@ from . import ops
 from .engine import OpenVLAEngine
 
 IGNORE_INDEX = -100
-_CACHE: Dict[Tuple[int, int, int], OpenVLAEngine] = {}
 
 
 def forward_all_rows(model, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
@@ -23,10 +22,8 @@ def forward_all_rows(model, input_ids: torch.Tensor, attention_mask: Optional[to
     """Returns (loss or None, logits fp32 [B, S, vocab], projector features bf16 [B, 256, D])."""
     dev = model.device
     B, L = input_ids.shape
-    key = (id(model.weights), B, L)
-    eng = _CACHE.get(key)
-    if eng is None:
-        eng = _CACHE[key] = OpenVLAEngine(model.weights, B, L, all_rows=True, use_mask=True)
+    # engines live on the model (LRU-bounded, PrismaticForConditionalGeneration._lru), never in a module global
+    eng = model._lru(model._forward_engines, (B, L), lambda: OpenVLAEngine(model.weights, B, L, all_rows=True, use_mask=True))
     P, S = model.dims.n_patches, eng.S
     eng.set_inputs(input_ids.to(dev), pixel_values.to(dev))
     if attention_mask is None:
@@ -39,7 +36,7 @@ def forward_all_rows(model, input_ids: torch.Tensor, attention_mask: Optional[to
     ops.run_all(eng.vision_ops + eng.projector_ops)
     proj = eng.x[:, 1:1 + P].clone()          # rows 1..256 are overwritten in place by the decoder layers
     ops.run_all(eng.prefill_ops)
-    logits = eng.logits_all.view(B, S, -1)
+    logits = eng.logits_all.view(B, S, -1).clone()      # fresh tensor like the reference's: the engine buffer is reused
     loss = None
     if labels is not None:
         lab = labels.to(dev)
@@ -51,5 +48,5 @@ def forward_all_rows(model, input_ids: torch.Tensor, attention_mask: Optional[to
         row_loss = torch.empty(B * S, dtype=torch.float32, device=dev)
         mean_cnt = torch.empty(2, dtype=torch.float32, device=dev)
         ops.cross_entropy(eng.logits_all, targets.view(-1), row_loss, mean_cnt, IGNORE_INDEX)
-        loss = mean_cnt[0]
+        loss = mean_cnt[0].clone()
     return loss, logits, proj

@@ -76,7 +76,9 @@ class LLMBackbone:
 
 
 class LLaMa2LLMBackbone(LLMBackbone):
-    """llama2.py:55-102 / base_llm.py:101-223 for `llama2-7b-pure`: hidden 4096, 32 layers, vocab padded to 32064."""
+    """llama2.py:55-102 / base_llm.py:101-223 for `llama2-7b-pure` (hidden 4096, 32 layers) and `llama2-13b-pure`
+    (hidden 5120, 40 layers; llama2.py:22-29): vocab padded to 32064."""
+    _WIDTHS = {"llama2-7b-pure": (4096, 32), "llama2-13b-pure": (5120, 40)}
 
     def __init__(self, llm_backbone_id: str, llm_max_length: int = 2048, hf_token: Optional[str] = None,
                  inference_mode: bool = False, use_flash_attention_2: bool = True, tokenizer: Any = None) -> None:
@@ -100,12 +102,12 @@ class LLaMa2LLMBackbone(LLMBackbone):
 
     @property
     def last_layer_finetune_modules(self) -> Sequence[str]:
-        n = 32 if self._vlm is None else self._vlm.dims.llm_layers
+        n = self._WIDTHS[self.identifier][1] if self._vlm is None else self._vlm.dims.llm_layers
         return ("language_model.model.embed_tokens", f"language_model.model.layers.{n - 1}", "language_model.lm_head")
 
     @property
     def embed_dim(self) -> int:
-        return 4096 if self._vlm is None else self._vlm.dims.llm_dim
+        return self._WIDTHS[self.identifier][0] if self._vlm is None else self._vlm.dims.llm_dim
 
     @property
     def pad_token_id(self) -> int:

@@ -55,23 +55,28 @@ def save_pretrained(model: OpenVLAForActionPrediction, save_directory: Union[str
     (d / "model.safetensors.index.json").write_text(json.dumps(index, indent=2))
 
 
-def from_pretrained(path: Union[str, Path], device: Union[str, torch.device] = "cuda:0",
-                    dims: Optional[VLADims] = None) -> OpenVLAForActionPrediction:
-    """`AutoModelForVision2Seq.from_pretrained(local_dir, trust_remote_code=True)` for a LOCAL HF export."""
+def load_hf_directory(cls, path: Union[str, Path], config=None, device: Union[str, torch.device, None] = None,
+                      dims: Optional[VLADims] = None):
+    """The body of `OpenVLAForActionPrediction.from_pretrained` (and of `AutoModelForVision2Seq.from_pretrained(local_dir,
+    trust_remote_code=True)` once register_auto_classes() ran) for a LOCAL HF export."""
     from safetensors.torch import load_file
     d = Path(path)
     if not (d / "config.json").exists():
         raise FileNotFoundError(f"`{path}` is not a local model directory (nothing is fetched from the hub)")
-    raw = json.loads((d / "config.json").read_text())
-    keep = ("vision_backbone_id", "llm_backbone_id", "arch_specifier", "use_fused_vision_backbone", "image_resize_strategy",
-            "text_config", "llm_max_length", "pad_token_id", "pad_to_multiple_of", "norm_stats", "n_action_bins")
-    tc = raw.get("text_config")
-    if isinstance(tc, dict):
-        raw["text_config"] = {k: v for k, v in tc.items() if k in (
-            "vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
-            "num_key_value_heads", "rms_norm_eps", "rope_theta", "max_position_embeddings", "pad_token_id", "hidden_act")}
-    cfg = OpenVLAConfig(**{k: raw[k] for k in keep if k in raw})
-    model = OpenVLAForActionPrediction(cfg, device=device, dims=dims)
+    if config is None:
+        raw = json.loads((d / "config.json").read_text())
+        keep = ("vision_backbone_id", "llm_backbone_id", "arch_specifier", "use_fused_vision_backbone", "image_resize_strategy",
+                "text_config", "llm_max_length", "pad_token_id", "pad_to_multiple_of", "norm_stats", "n_action_bins")
+        tc = raw.get("text_config")
+        if isinstance(tc, dict):
+            raw["text_config"] = {k: v for k, v in tc.items() if k in (
+                "vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
+                "num_key_value_heads", "rms_norm_eps", "rope_theta", "max_position_embeddings", "pad_token_id", "hidden_act")}
+        kw = {k: raw[k] for k in keep if k in raw}
+        if not issubclass(cls.config_class, OpenVLAConfig):
+            kw.pop("norm_stats", None); kw.pop("n_action_bins", None)
+        config = cls.config_class(**kw)
+    model = cls(config, device=device, dims=dims)
     files = sorted(d.glob("*.safetensors"))
     if not files:
         raise FileNotFoundError(f"no *.safetensors under `{path}`")
@@ -89,7 +94,13 @@ def from_pretrained(path: Union[str, Path], device: Union[str, torch.device] = "
     missing = [n for n in model.weights.placements if n not in seen]
     if missing:
         raise KeyError(f"checkpoint is missing {len(missing)} tensors, e.g. {missing[:3]}")
-    return model
+    return model.eval()
+
+
+def from_pretrained(path: Union[str, Path], device: Union[str, torch.device, None] = None,
+                    dims: Optional[VLADims] = None) -> OpenVLAForActionPrediction:
+    """`AutoModelForVision2Seq.from_pretrained(local_dir, trust_remote_code=True)` for a LOCAL HF export."""
+    return load_hf_directory(OpenVLAForActionPrediction, path, device=device, dims=dims)
 
 
 # ---- native layout -----------------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@ VISION_BACKBONES = {
 }
 LLM_BACKBONES = {
     "llama2-7b-pure": {"cls": LLaMa2LLMBackbone, "kwargs": {}},
+    "llama2-13b-pure": {"cls": LLaMa2LLMBackbone, "kwargs": {}},       # BASELINE configs[4] (models/materialize.py:57)
 }
 
 

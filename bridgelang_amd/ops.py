@@ -56,6 +56,15 @@ class Op:
             _lib.check(rc, self.name)
 
 
+def glue(name: str, fn, keep: tuple = ()) -> Op:
+    """A host-side index/copy step (torch data movement on the current stream, no arithmetic) wrapped as an Op so it can
+    sit inside an op plan; `fn()` runs when the plan reaches it."""
+    def call(stream):
+        fn()
+        return 0
+    return Op(name, call, (), tuple(keep))
+
+
 def run_all(ops: Sequence[Op]) -> None:
     s = _stream()
     for op in ops:
@@ -355,7 +364,8 @@ def attention_decode(q, k, v, o, *, B: int, H: int, Skv: int, head_dim: int, q_s
 
 def attention_decode_rope(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, o: torch.Tensor,
                           cos: torch.Tensor, sin: torch.Tensor, *, B: int, H: int, head_dim: int, pos: int,
-                          scale: Optional[float] = None, key_mask: Optional[torch.Tensor] = None, run: bool = True) -> Op:
+                          scale: Optional[float] = None, key_mask: Optional[torch.Tensor] = None,
+                          rope_pos: Optional[torch.Tensor] = None, run: bool = True) -> Op:
     """One decode step's attention with RoPE and the KV-cache append fused: qkv [B, 3*H*hd] is the step's fused
     projection (q | k | v), caches [B, H, cache_len, hd]; rotates q and k at `pos`, writes k', v to cache row `pos`,
     attends over keys 0..pos, writes o [B, H*hd]."""
@@ -372,6 +382,15 @@ def attention_decode_rope(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: tor
     cs = (H * cache_len * head_dim, cache_len * head_dim, head_dim)
     d = _attn_desc(qkv, k_cache, v_cache, o, B, H, 1, pos + 1, head_dim, (3 * D, head_dim, 3 * D), cs, cs,
                    (D, head_dim, D), False, scale, key_mask)
+    if rope_pos is not None:     # right-padded prompts: per-sequence rotation position (int32 [B]), shared cache row
+        if rope_pos.dtype != torch.int32 or not rope_pos.is_cuda or rope_pos.numel() != B or not rope_pos.is_contiguous():
+            raise TypeError("attention_decode_rope: rope_pos must be a contiguous CUDA/HIP int32 tensor [B]")
+        op = Op("bl_attention_decode_rope_pos_bf16", lib.bl_attention_decode_rope_pos_bf16,
+                (C.byref(d), cos.data_ptr(), sin.data_ptr(), pos, rope_pos.data_ptr()),
+                (d, qkv, k_cache, v_cache, o, cos, sin, key_mask, rope_pos))
+        if run:
+            op.run()
+        return op
     op = Op("bl_attention_decode_rope_bf16", lib.bl_attention_decode_rope_bf16,
             (C.byref(d), cos.data_ptr(), sin.data_ptr(), pos), (d, qkv, k_cache, v_cache, o, cos, sin, key_mask))
     if run:

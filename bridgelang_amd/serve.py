@@ -25,6 +25,7 @@ copies of their last request.
 from __future__ import annotations
 
 import base64
+from collections import OrderedDict
 import json
 import logging
 import queue
@@ -105,13 +106,17 @@ class OpenVLAServer:
 
     def __init__(self, vla: Any, processor: Any, openvla_path: Union[str, Path] = "openvla/openvla-7b",
                  max_batch: int = 16, max_wait_ms: float = 2.0, norm_stats_path: Optional[Union[str, Path]] = None,
-                 pipeline_batch: Optional[int] = None):
+                 pipeline_batch: Optional[int] = None, max_pipelines: int = 2):
         self.vla, self.processor, self.openvla_path = vla, processor, str(openvla_path)
         self.max_batch, self.max_wait = int(max_batch), float(max_wait_ms) * 1e-3
         self.pipeline_batch = pipeline_batch
         if pipeline_batch:
             self.max_batch = int(pipeline_batch)
-        self._pipes: Dict[int, Any] = {}          # prompt length → (StaggeredDecodePipeline, {tick: requests})
+        # prompt length → (StaggeredDecodePipeline, {tick: requests}); least recently used first. A pipeline is 7 engines
+        # (KV caches + activations, ≈ 3 GB each at B = 16 on 7B) + 7 graphs, and instruction lengths vary per request, so
+        # only `max_pipelines` are kept; the plain path's engines are bounded the same way on the model (engine LRU).
+        self._pipes: "OrderedDict[int, Any]" = OrderedDict()
+        self.max_pipelines = max(1, int(max_pipelines))
         stats = Path(norm_stats_path) if norm_stats_path else Path(self.openvla_path) / "dataset_statistics.json"
         if stats.is_file():                       # fine-tuned run directory (deploy.py:86-89)
             self.vla.norm_stats = json.loads(stats.read_text())
@@ -178,10 +183,18 @@ class OpenVLAServer:
     # -- throughput mode: one pipeline per prompt length --
     def _pipe_for(self, L: int):
         from .pipeline import StaggeredDecodePipeline
-        if L not in self._pipes:
-            pipe = StaggeredDecodePipeline(self.vla.weights, self.pipeline_batch, L)
-            pipe.capture()
-            self._pipes[L] = (pipe, {})
+        if L in self._pipes:
+            self._pipes.move_to_end(L)
+            return self._pipes[L]
+        while len(self._pipes) >= self.max_pipelines:       # evict the least recently used pipeline (always drained:
+            old_len, (old, infl) = next(iter(self._pipes.items()))      # _serve_pipelined drains before switching lengths)
+            assert not infl, "evicting a pipeline with batches in flight"
+            del self._pipes[old_len]
+            del old
+            torch.cuda.empty_cache()
+        pipe = StaggeredDecodePipeline(self.vla.weights, self.pipeline_batch, L)
+        pipe.capture()
+        self._pipes[L] = (pipe, {})
         return self._pipes[L]
 
     def _resolve(self, reqs: List[_Request], token_ids: torch.Tensor) -> None:
@@ -213,6 +226,10 @@ class OpenVLAServer:
                 self._drain()
                 return
             try:
+                if self.vla.get_action_dim(batch[0].unnorm_key) != 7:
+                    # the pipelines decode 7 tokens; other action dimensions go through the plain engine
+                    self._run_plain(batch)
+                    continue
                 ids = self.vla.with_empty_token(torch.cat([r.input_ids for r in batch], dim=0).to(dev))
                 pv = torch.cat([r.pixel_values for r in batch], dim=0).to(dev, torch.bfloat16)
                 pad = self.pipeline_batch - len(batch)
@@ -242,17 +259,27 @@ class OpenVLAServer:
             batch = self._take_batch()
             if batch is None:
                 return
-            try:
-                ids = torch.cat([r.input_ids for r in batch], dim=0)
-                pv = torch.cat([r.pixel_values for r in batch], dim=0)
-                actions = np.asarray(self.vla.predict_action(input_ids=ids, pixel_values=pv, unnorm_key=batch[0].unnorm_key,
-                                                             do_sample=False))
-                actions = actions.reshape(len(batch), -1)
-                self.batch_sizes.append(len(batch))
-                for r, a in zip(batch, actions):
-                    r.future.set_result(a)
-            except Exception as e:   # noqa: BLE001 — delivered to every waiting request
-                for r in batch:
+            self._run_plain(batch)
+
+    def _run_plain(self, batch: List[_Request]) -> None:
+        """One predict_action call for the batch. Batch sizes are rounded up to 1 / 2 / 4 / 8 / 16 … with copies of the
+        last request, so the model builds (and its engine LRU holds) few distinct engines."""
+        try:
+            n = len(batch)
+            size = 1
+            while size < n:
+                size *= 2
+            ids = torch.cat([r.input_ids for r in batch] + [batch[-1].input_ids] * (size - n), dim=0)
+            pv = torch.cat([r.pixel_values for r in batch] + [batch[-1].pixel_values] * (size - n), dim=0)
+            actions = np.asarray(self.vla.predict_action(input_ids=ids, pixel_values=pv, unnorm_key=batch[0].unnorm_key,
+                                                         do_sample=False))
+            actions = actions.reshape(size, -1)[:n]
+            self.batch_sizes.append(n)
+            for r, a in zip(batch, actions):
+                r.future.set_result(a)
+        except Exception as e:   # noqa: BLE001 — delivered to every waiting request
+            for r in batch:
+                if not r.future.done():
                     r.future.set_exception(e)
 
     def close(self) -> None:

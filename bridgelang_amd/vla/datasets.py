@@ -75,3 +75,20 @@ class DummyDataset(torch.utils.data.Dataset):
         action = np.asarray(rng.rand(7), dtype=np.float32)
         return build_sample(self.action_tokenizer, self.base_tokenizer, self.image_transform, self.prompt_builder_fn,
                             image, "do something spectacular", action)
+
+
+class EpochIterable(torch.utils.data.IterableDataset):
+    """A map-style dataset presented as the endless IterableDataset `run_vla_training` expects (the RLDS loader repeats
+    forever, base_strategy.py:259-266); `len()` is one epoch, which sizes the LR schedule."""
+
+    def __init__(self, dataset) -> None:
+        self.dataset = dataset
+        self.dataset_statistics = getattr(dataset, "dataset_statistics", None)
+
+    def __len__(self) -> int:
+        return len(self.dataset)
+
+    def __iter__(self):
+        while True:
+            for i in range(len(self.dataset)):
+                yield self.dataset[i]

@@ -183,6 +183,14 @@ int bl_rope_bf16(bl_bf16* qkv, int64_t ld, int32_t B, int32_t S, int32_t H, int3
  * are written to cache row `pos` of d->k / d->v, and attention runs over keys 0..pos (d->Skv must equal pos + 1). */
 int bl_attention_decode_rope_bf16(const bl_attn_desc* d, const bl_bf16* cos_tab, const bl_bf16* sin_tab, int32_t pos,
                                   void* stream);
+/* bl_attention_decode_rope_bf16 for a batch of RIGHT-PADDED prompts (HF generation with an attention mask,
+ * modeling_prismatic.py:387-390 + transformers' position_ids = cumsum(mask) - 1): the new token's k / v go to cache row
+ * `pos` for every sequence, but q and k are rotated at the per-sequence position rope_pos[b] (device int32 [B]) = the
+ * number of real tokens before it; d->key_mask [B, pos + 1] hides the pad rows of the cache. Results per sequence equal
+ * the un-padded sequence's. */
+int bl_attention_decode_rope_pos_bf16(const bl_attn_desc* d, const bl_bf16* cos_tab, const bl_bf16* sin_tab, int32_t pos,
+                                      const int32_t* rope_pos, void* stream);
+
 /* n_groups (<= 8) decode iterations of DIFFERENT batches in one launch (continuous batching, pipeline.py): rows
  * g*B .. (g+1)*B-1 of the fused qkv / output buffers belong to group g, which has its own KV caches
  * k_caches[g] / v_caches[g] ([B, H, cache_len, 128], strides from d->k_* / d->v_*) and position pos[g]. The three arrays
