@@ -27,7 +27,7 @@ struct AttnArgs {
   float scale_log2e;
   float* lse;      // optional [B*H, lse_rs] base-2 log-sum-exp of the scaled scores (training forward); +inf for empty rows
   int lse_rs;
-  const int* rope_pos;   // decode kernel, optional [B]: per-sequence RoPE position (right-padded prompts); NULL = the cache row
+  const int* rope_pos;   // decode kernel, optional [B]: per-sequence position (right-padded prompts) = cache row, rotation, length - 1
   // fused RoPE + KV-cache write (whole-sequence kernel, head_dim 128): q / k are rotated while they are loaded, the rotated
   // k and v rows are also written to the caches [B, H, cache_len, 128] at positions pos0 + key
   const uint16_t* cos_tab; const uint16_t* sin_tab; uint16_t* k_cache; uint16_t* v_cache; int cache_len, pos0;
@@ -469,6 +469,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p, const uint
   const int ks = lane >> 4, dc = lane & 15;
   const long qoff = (long)b * p.q_bs + (long)h * p.q_hs;
   const uint8_t* mrow = p.mask ? p.mask + (long)b * p.mask_bs : nullptr;
+  if (ROPE && p.rope_pos) {   // right-padded batch: this sequence's own position = its cache row, rotation angle and length
+    pos = p.rope_pos[b];
+    p.Skv = pos + 1;
+  }
   const int n = p.Skv, n_cache = ROPE ? n - 1 : n;
   uint16_t* kc = const_cast<uint16_t*>(p.k) + (long)b * p.k_bs + (long)h * p.k_hs + dc * 8;
   uint16_t* vc = const_cast<uint16_t*>(p.v) + (long)b * p.v_bs + (long)h * p.v_hs + dc * 8;
@@ -477,9 +481,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p, const uint
   float knv[8], vnv[8];   // ROPE: rotated new key / new value chunk (bf16 values)
   if constexpr (ROPE) {
     // half-split rotation: chunk dc pairs with chunk dc ^ 8; out = bf16(bf16(own*cos) + bf16(±partner*sin))
-    const int rp = p.rope_pos ? p.rope_pos[b] : pos;   // rotation angle index; the cache row stays `pos`
-    const u32x4_t cq = *(const u32x4_t*)(cos_tab + (long)rp * 64 + (dc & 7) * 8);
-    const u32x4_t sq = *(const u32x4_t*)(sin_tab + (long)rp * 64 + (dc & 7) * 8);
+    const u32x4_t cq = *(const u32x4_t*)(cos_tab + (long)pos * 64 + (dc & 7) * 8);
+    const u32x4_t sq = *(const u32x4_t*)(sin_tab + (long)pos * 64 + (dc & 7) * 8);
     const float sgn = dc < 8 ? -1.f : 1.f;
     const u32x4_t q_own = *(const u32x4_t*)(p.q + qoff + dc * 8), q_par = *(const u32x4_t*)(p.q + qoff + (dc ^ 8) * 8);
     const u32x4_t k_own = *(const u32x4_t*)(kn + qoff + dc * 8), k_par = *(const u32x4_t*)(kn + qoff + (dc ^ 8) * 8);

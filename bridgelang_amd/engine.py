@@ -291,7 +291,9 @@ class OpenVLAEngine:
         for l, lw in enumerate(w.layers):
             if fused:
                 plan.append(self._g(self.xd, lw.qkv_w, self.qkvd, EPI_NONE, a_norm=(lw.ln1, d.rms_eps), run=False))
-                pad_kw = dict(key_mask=self.cache_mask, rope_pos=self.rope_pos[t]) if self.padded else {}
+                # padded: every sequence appends at its own position (over its pad rows): the cache layout, and with
+                # it every sum, is the one of the sequence's un-padded run
+                pad_kw = dict(rope_pos=self.rope_pos[t]) if self.padded else {}
                 plan.append(ops.attention_decode_rope(self.qkvd, self.k_cache[l], self.v_cache[l], self.aod, self.cos,
                                                       self.sin, B=B, H=H, head_dim=hd, pos=pos, run=False, **pad_kw))
             else:

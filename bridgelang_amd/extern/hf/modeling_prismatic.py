@@ -276,10 +276,24 @@ class OpenVLAForActionPrediction(PrismaticForConditionalGeneration):
     def predict_action(self, input_ids: Optional[torch.LongTensor] = None, unnorm_key: Optional[str] = None,
                        **kwargs: Any) -> np.ndarray:
         """ids → 7 greedy action tokens → bin centres → un-normalised 7-DoF action (reference :506-536)."""
-        input_ids = self.with_empty_token(input_ids.to(self.device))
-        if kwargs.get("attention_mask") is not None and kwargs["attention_mask"].shape[1] != input_ids.shape[1]:
-            m = kwargs["attention_mask"].to(self.device)
-            kwargs["attention_mask"] = torch.cat((m, torch.ones_like(m[:, :1])), dim=1)
+        input_ids = input_ids.to(self.device)
+        m = kwargs.get("attention_mask")
+        if m is not None and not bool(m.bool().all()):
+            # right-padded batch: the empty token goes behind each sequence's last REAL token (one more column)
+            m = m.to(self.device).long()
+            n = m.sum(dim=1)
+            rows = torch.arange(input_ids.shape[0], device=self.device)
+            need = input_ids[rows, n - 1] != 29871
+            ids = torch.cat((input_ids, torch.full_like(input_ids[:, :1], self.pad_token_id)), dim=1)
+            m = torch.cat((m, torch.zeros_like(m[:, :1])), dim=1)
+            ids[rows[need], n[need]] = 29871
+            m[rows[need], n[need]] = 1
+            input_ids, kwargs["attention_mask"] = ids, m
+        else:
+            input_ids = self.with_empty_token(input_ids)
+            if m is not None and m.shape[1] != input_ids.shape[1]:
+                m = m.to(self.device)
+                kwargs["attention_mask"] = torch.cat((m, torch.ones_like(m[:, :1])), dim=1)
         n = self.get_action_dim(unnorm_key)
         generated = self.generate(input_ids, max_new_tokens=n, **kwargs)
         return self.actions_from_token_ids(generated[:, -n:].cpu().numpy(), unnorm_key)

@@ -231,7 +231,10 @@ class ShardedOptimizerStrategy:
             if ids.shape[0] != self.per_device_batch_size:
                 continue                                                    # ragged tail of a finite iterable
             eng = self._ensure_engine(ids.shape[1])
-            eng.set_batch(ids, batch["attention_mask"], batch["pixel_values"], batch["labels"])
+            pv = batch["pixel_values"]
+            if isinstance(pv, dict):          # the native fused backbone's transform yields {"dino", "siglip"} (dinosiglip_vit.py:33-40)
+                pv = torch.cat([pv["dino"], pv["siglip"]], dim=1)
+            eng.set_batch(ids, batch["attention_mask"], pv, batch["labels"])
             loss = eng.forward(graph=True)                    # static plans replayed as HIP graphs
             metrics.commit(loss=loss)
             eng.backward(graph=True)                          # (sharded runs keep the backward eager: per-bucket collectives)

@@ -1,0 +1,75 @@
+"""Eval-time image preprocessing of the robot evaluation loops, host side:
+
+  * `center_crop_and_resize` — `get_vla_action(..., center_crop=True)` (experiments/robot/openvla_utils.py:81-155): crop the
+    centre box of area `crop_scale` × image area (side × sqrt(crop_scale)) and resize it back with
+    `tf.image.crop_and_resize` semantics (bilinear samples at box corners inclusive, (out-1) intervals), through
+    float32 in [0, 1] and back to uint8 with TF's saturating `convert_image_dtype` (× 255.5, truncate).
+  * `resize_image` — LIBERO's `resize_image` (experiments/robot/libero/libero_utils.py:33-47): JPEG encode → decode
+    (as the RLDS dataset builder stores frames), Lanczos-3 antialiased resize, round, clip to uint8.
+
+The reference runs both through TensorFlow, which is absent here and on the GPU box: the arithmetic below restates the
+TF ops' documented definitions with numpy / Pillow (JPEG codec and Lanczos filter are Pillow's, TF's differ in rounding
+details) — PARITY UNPINNED against TF; the tests check the defining properties (geometry, identity cases, value ranges).
+Frames then go through `PrismaticImageProcessor` (bit-exact vs Pillow, on the CPU or on the GPU)."""
+from __future__ import annotations
+
+import io
+from typing import Tuple
+
+import numpy as np
+from PIL import Image
+
+
+def _to_float(img_u8: np.ndarray) -> np.ndarray:
+    """tf.image.convert_image_dtype(uint8 → float32): x / 255."""
+    return img_u8.astype(np.float32) * np.float32(1.0 / 255.0)
+
+
+def _to_uint8_saturate(img_f: np.ndarray) -> np.ndarray:
+    """tf.image.convert_image_dtype(float32 → uint8, saturate=True): x * (255 + 0.5), saturate, truncate."""
+    return np.clip(img_f * np.float32(255.5), 0.0, 255.0).astype(np.uint8)
+
+
+def crop_and_resize_bilinear(img_f: np.ndarray, box: Tuple[float, float, float, float], out_hw: Tuple[int, int]) -> np.ndarray:
+    """tf.image.crop_and_resize for one image [H, W, C] float32 and one normalised box (y1, x1, y2, x2): output pixel
+    (i, j) samples the input at y = y1·(H-1) + i·(y2-y1)·(H-1)/(out_h-1) (likewise x), bilinear, 0 outside the image."""
+    H, W, _ = img_f.shape
+    oh, ow = out_hw
+    y1, x1, y2, x2 = box
+    ys = y1 * (H - 1) + np.arange(oh, dtype=np.float32) * ((y2 - y1) * (H - 1) / max(oh - 1, 1))
+    xs = x1 * (W - 1) + np.arange(ow, dtype=np.float32) * ((x2 - x1) * (W - 1) / max(ow - 1, 1))
+    if oh == 1:
+        ys = np.array([0.5 * (y1 + y2) * (H - 1)], dtype=np.float32)
+    if ow == 1:
+        xs = np.array([0.5 * (x1 + x2) * (W - 1)], dtype=np.float32)
+    y0, x0 = np.floor(ys).astype(np.int64), np.floor(xs).astype(np.int64)
+    wy, wx = (ys - y0).astype(np.float32)[:, None, None], (xs - x0).astype(np.float32)[None, :, None]
+    inside = ((ys >= 0) & (ys <= H - 1))[:, None, None] & ((xs >= 0) & (xs <= W - 1))[None, :, None]
+    y0c, y1c = np.clip(y0, 0, H - 1), np.clip(y0 + 1, 0, H - 1)
+    x0c, x1c = np.clip(x0, 0, W - 1), np.clip(x0 + 1, 0, W - 1)
+    top = img_f[y0c][:, x0c] * (1 - wx) + img_f[y0c][:, x1c] * wx
+    bot = img_f[y1c][:, x0c] * (1 - wx) + img_f[y1c][:, x1c] * wx
+    return np.where(inside, top * (1 - wy) + bot * wy, np.float32(0.0)).astype(np.float32)
+
+
+def center_crop_and_resize(image_u8: np.ndarray, crop_scale: float = 0.9, out_hw: Tuple[int, int] = (224, 224)) -> np.ndarray:
+    """openvla_utils.py:127-155: uint8 [H, W, 3] → uint8 [out_h, out_w, 3]; the crop keeps sqrt(crop_scale) of each side."""
+    side = float(np.clip(np.sqrt(crop_scale), 0.0, 1.0))
+    off = (1.0 - side) / 2.0
+    out = crop_and_resize_bilinear(_to_float(np.asarray(image_u8)), (off, off, off + side, off + side), out_hw)
+    return _to_uint8_saturate(np.clip(out, 0.0, 1.0))
+
+
+def jpeg_round_trip(image_u8: np.ndarray, quality: int = 95) -> np.ndarray:
+    """tf.image.encode_jpeg (defaults: quality 95, chroma down-sampling) followed by decode."""
+    buf = io.BytesIO()
+    Image.fromarray(np.asarray(image_u8, dtype=np.uint8)).save(buf, format="JPEG", quality=quality, subsampling="4:2:0")
+    return np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))
+
+
+def resize_image(image_u8: np.ndarray, resize_size: Tuple[int, int]) -> np.ndarray:
+    """libero_utils.py:33-47: JPEG round trip, Lanczos-3 antialiased resize to (height, width), round + clip to uint8."""
+    assert isinstance(resize_size, tuple)
+    img = jpeg_round_trip(image_u8)
+    h, w = resize_size
+    return np.asarray(Image.fromarray(img).resize((w, h), Image.LANCZOS), dtype=np.uint8)

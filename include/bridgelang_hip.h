@@ -184,10 +184,11 @@ int bl_rope_bf16(bl_bf16* qkv, int64_t ld, int32_t B, int32_t S, int32_t H, int3
 int bl_attention_decode_rope_bf16(const bl_attn_desc* d, const bl_bf16* cos_tab, const bl_bf16* sin_tab, int32_t pos,
                                   void* stream);
 /* bl_attention_decode_rope_bf16 for a batch of RIGHT-PADDED prompts (HF generation with an attention mask,
- * modeling_prismatic.py:387-390 + transformers' position_ids = cumsum(mask) - 1): the new token's k / v go to cache row
- * `pos` for every sequence, but q and k are rotated at the per-sequence position rope_pos[b] (device int32 [B]) = the
- * number of real tokens before it; d->key_mask [B, pos + 1] hides the pad rows of the cache. Results per sequence equal
- * the un-padded sequence's. */
+ * modeling_prismatic.py:387-390 + transformers' position_ids = cumsum(mask) - 1): sequence b's new token sits at ITS
+ * position rope_pos[b] (device int32 [B]) = the number of real tokens before it — that is its rotation angle, the cache
+ * row its k / v are written to (over the pad rows' entries) and its key count - 1; `pos` = max_b rope_pos[b] bounds the
+ * cache. The cache of every sequence is then laid out exactly as in its own un-padded run: identical results, bit for
+ * bit. */
 int bl_attention_decode_rope_pos_bf16(const bl_attn_desc* d, const bl_bf16* cos_tab, const bl_bf16* sin_tab, int32_t pos,
                                       const int32_t* rope_pos, void* stream);
 

@@ -34,13 +34,13 @@ def _bf16_bits_to_f32(a: np.ndarray) -> torch.Tensor:
 _W = {}
 
 
-def _weights(recipe, dev):
-    """one 15 GB checkpoint per recipe, shared by the tests of this module"""
+def _weights(recipe, dev, model="7b"):
+    """one checkpoint (15 GB at 7B, 26 GB at 13B) per (recipe, model), shared by the full-size tests"""
     from bridgelang_amd import weights as W
-    if recipe not in _W:
-        dims = W.openvla_7b_dims()
-        _W[recipe] = (dims, W.allocate(dims, dev).fill_synthetic(seed=0, recipe=recipe))
-    return _W[recipe]
+    if (recipe, model) not in _W:
+        dims = W.openvla_7b_dims() if model == "7b" else W.prism_13b_dims()
+        _W[(recipe, model)] = (dims, W.allocate(dims, dev).fill_synthetic(seed=0, recipe=recipe))
+    return _W[(recipe, model)]
 
 
 def _run(recipe, batch, dev):

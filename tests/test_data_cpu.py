@@ -78,3 +78,35 @@ def test_sample_construction_and_collation():
     batch = PaddedCollatorForActionPrediction(tok.vocab_size and 2048, tok.pad_token_id)([ds[0], ds[1], s])
     assert batch["pixel_values"].shape == (3, 6, 224, 224) and batch["input_ids"].shape == batch["labels"].shape
     assert torch.equal(batch["attention_mask"], batch["input_ids"].ne(32000))
+
+
+def test_eval_time_preprocessing_properties():
+    """openvla_utils.py:81-155 / libero_utils.py:33-47 restated without TensorFlow (absent: parity unpinned): defining
+    properties of the centre crop + resize and of the JPEG / Lanczos resize."""
+    from bridgelang_amd.vla.eval_preprocess import (center_crop_and_resize, crop_and_resize_bilinear, jpeg_round_trip,
+                                                    resize_image)
+    g = np.random.RandomState(0)
+    img = g.randint(0, 256, (224, 224, 3), dtype=np.uint8)
+    # crop_scale = 1 at the same size: sample points land on the pixel centres → the image itself (× 255.5 truncation)
+    same = center_crop_and_resize(img, crop_scale=1.0, out_hw=(224, 224))
+    assert same.shape == (224, 224, 3) and same.dtype == np.uint8 and np.array_equal(same, img)
+    # a constant image stays constant; the crop is centred: a centred bright square covers more of the output
+    const = np.full((100, 120, 3), 77, np.uint8)
+    assert (center_crop_and_resize(const, 0.9) == 77).all()
+    sq = np.zeros((200, 200, 3), np.uint8); sq[50:150, 50:150] = 255
+    out = center_crop_and_resize(sq, 0.9, (200, 200))
+    assert out[100, 100, 0] == 255 and out[2, 2, 0] == 0
+    frac_in, frac_out = (sq > 127).mean(), (out > 127).mean()
+    assert abs(frac_out / frac_in - 1 / 0.9) < 0.03                       # area ratio = 1 / crop_scale
+    # corners of the box are sampled exactly (crop_and_resize uses out-1 intervals)
+    ramp = np.tile(np.arange(101, dtype=np.float32)[None, :, None], (5, 1, 1))
+    r = crop_and_resize_bilinear(ramp, (0.0, 0.1, 1.0, 0.9), (5, 9))
+    assert np.allclose(r[0, :, 0], np.linspace(10, 90, 9), atol=1e-4)
+    assert (crop_and_resize_bilinear(ramp, (0.0, -0.5, 1.0, 0.5), (2, 3))[0, 0] == 0).all()    # outside → 0
+    # JPEG round trip is lossy but close on a smooth image; Lanczos resize keeps range / shape / dtype
+    yy, xx = np.mgrid[0:256, 0:256]
+    smooth = np.stack([yy, xx, (yy + xx) // 2], -1).astype(np.uint8)
+    jt = jpeg_round_trip(smooth)
+    assert jt.shape == smooth.shape and np.abs(jt.astype(int) - smooth.astype(int)).mean() < 2.0
+    rs = resize_image(smooth, (224, 224))
+    assert rs.shape == (224, 224, 3) and rs.dtype == np.uint8 and abs(int(rs[112, 112, 0]) - 128) <= 3

@@ -24,14 +24,17 @@ pytestmark = pytest.mark.gpu
 BLOCKS = 2
 
 
-@pytest.mark.parametrize("recipe", ["decisive", "init"])
-def test_every_kernel_of_the_first_blocks_vs_oracle_full_size(dev, recipe):
+@pytest.mark.parametrize("recipe,model", [("decisive", "7b"), ("init", "7b"), ("init", "13b")])
+def test_every_kernel_of_the_first_blocks_vs_oracle_full_size(dev, recipe, model):
+    """model = "13b": BASELINE configs[4]'s composition (dinosiglip-vit-so-224px + llama2-13b-pure: hidden 5120, 40 heads,
+    inter 13824) — the decoder kernels at 13B widths (K = 5120 / 13824 GEMMs, 40-head attention); the towers are the 7B ones."""
     from bridgelang_amd import ops, weights as W
     from bridgelang_amd.engine import OpenVLAEngine
     from test_cfg_7b_golden_gpu import _weights
     from test_full_size_gpu import make_inputs
-    dims, w = _weights(recipe, dev)
+    dims, w = _weights(recipe, dev, model)
     eng = OpenVLAEngine(w, 1, 32)
+    towers = ((w.dino, eng.dino_ops, eng.vbuf[0]), (w.siglip, eng.siglip_ops, eng.vbuf[1])) if model == "7b" else ()
     ids, pv = make_inputs(1, 32, 0)
     eng.set_inputs(ids.to(dev), pv.to(dev))
     specs = {s.name: s for s in W.tensor_specs(dims, recipe)}
@@ -49,7 +52,7 @@ def test_every_kernel_of_the_first_blocks_vs_oracle_full_size(dev, recipe):
                      (d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()))
 
     cpu = lambda t: t.float().cpu()
-    for tw, plan, vb in ((w.dino, eng.dino_ops, eng.vbuf[0]), (w.siglip, eng.siglip_ops, eng.vbuf[1])):
+    for tw, plan, vb in towers:
         t = tw.dims
         Tn, Dm, Hp, hd = t.tokens, t.dim, t.mlp_pad, t.head_dim
         x = vb["x"][:Tn * Dm].view(1, Tn, Dm); h = vb["h"][:Tn * Dm].view(1, Tn, Dm); ao = vb["ao"][:Tn * Dm].view(1, Tn, Dm)
@@ -109,9 +112,9 @@ def test_every_kernel_of_the_first_blocks_vs_oracle_full_size(dev, recipe):
         o7[6].run(); torch.cuda.synchronize()
         show(f"L{l} down+res", eng.x, P.rb(x1 + R.linear(P, c_in, g("mlp.down_proj.weight"))))
 
-    print(f"\n{recipe}: per-op parity at 7B width on real activations (op, bit-equal fraction, max|d|/max, rms(d)/rms)")
+    print(f"\n{recipe} {model}: per-op parity at full width on real activations (op, bit-equal fraction, max|d|/max, rms(d)/rms)")
     for tag, eq, mx, rms in rows:
         print(f"  {tag:34s} {eq:.4f}  {mx:.2e}  {rms:.2e}")
-    assert len(rows) == 2 * BLOCKS * 7 + BLOCKS * 8
+    assert len(rows) == len(towers) * BLOCKS * 7 + BLOCKS * 8
     for tag, eq, mx, rms in rows:
         assert eq >= 0.999 and rms <= 1e-4 and mx <= 2 ** -7, (tag, eq, mx, rms)
