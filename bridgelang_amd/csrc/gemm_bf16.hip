@@ -171,6 +171,10 @@ __global__ __launch_bounds__(256) void gemm128_kernel(GemmArgs p) {
 // NST-stage LDS-DMA ring with NST-1 K-tiles in flight behind a counted vmcnt and ONE barrier per K-step. The leftover
 // round has at most one workgroup per CU, so nothing else hides the HBM/L2 latency — the two-stage gemm128 loop spent
 // ≈ 3/4 of every K-step waiting there. K order per output = the big kernel's (bit-identical results).
+// Stand-alone mode (p.tail_base < 0): the same loop as the main kernel of problems whose 160 × 128 tiles fit ONE round of
+// 256 CUs — the narrow ViT layers at 16 images (attn.proj / mlp.fc2 / patch embed: M = 4176 or 4096, N = 1024 or 1152:
+// 216 / 234 tiles; 160 divides the ragged M with 1.5–3.4 % waste where 128-row tiles need 264 / 288 > 256 workgroups) —
+// where gemm128's one-stage prefetch left a lone workgroup per CU waiting on every K-step (fc2: 65 µs → see DESIGN).
 // ======================================================================================================================
 template <int EPI, int BM, int BN, int NST, int WM = 2>
 __global__ __launch_bounds__(WM * 128) void gemm_tail_kernel(GemmArgs p) {
@@ -185,10 +189,18 @@ __global__ __launch_bounds__(WM * 128) void gemm_tail_kernel(GemmArgs p) {
   // with the plain order the SUBS pieces of a tile land on SUBS different L2s and every one of them fetches the same rows
   const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
   const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-  int tm, tn;
-  lin_to_tile(p, p.tail_base + lin / SUBS, tm, tn);
-  const int sub = lin % SUBS;
-  const int m0 = tm * 256 + (sub / SUB_N) * BM, n0 = tn * 256 + (sub % SUB_N) * BN;
+  int m0, n0;
+  if (p.tail_base >= 0) {
+    int tm, tn;
+    lin_to_tile(p, p.tail_base + lin / SUBS, tm, tn);
+    const int sub = lin % SUBS;
+    m0 = tm * 256 + (sub / SUB_N) * BM, n0 = tn * 256 + (sub % SUB_N) * BN;
+  } else {
+    // stand-alone mode: the whole problem as BM × BN tiles (p.tiles_n of them per row panel), one tile per workgroup and —
+    // the launcher's condition — at most one workgroup per CU. Column tiles of a row panel are neighbours in `lin`, so an
+    // XCD's contiguous run re-uses its activation panels from L2.
+    m0 = (lin / p.tiles_n) * BM, n0 = (lin % p.tiles_n) * BN;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -1074,6 +1086,8 @@ int set_lds_attr() {
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 192 * ROW_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tail_kernel<EPI, 64, 64, 4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * ROW_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tail_kernel<EPI, 160, 128, 4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 288 * ROW_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mid2_kernel<EPI, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             3 * (160 * ROW_BYTES + 4096)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mid2_kernel<EPI, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1157,6 +1171,19 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     BL_CHECK_LAUNCH();
     return BL_OK;
   }
+  static const bool no_ring160 = getenv("BL_GEMM_NO_RING160") != nullptr;      // A/B aid
+  if (!big && !force && !no_ring160 && p.K >= 512) {
+    // one round of 160 × 128 tiles on the ring-buffered kernel when that covers the problem with ≥ 3/4 of the CUs busy
+    const int t160 = ((p.M + 159) / 160) * ((p.N + 127) / 128);
+    if (t160 <= CUS && t160 >= (3 * CUS) / 4) {
+      p.tiles_m = (p.M + 159) / 160;
+      p.tiles_n = (p.N + 127) / 128;
+      p.tail_base = -1;
+      hipLaunchKernelGGL((gemm_tail_kernel<EPI, 160, 128, 4>), dim3(t160), dim3(256), 4 * 288 * ROW_BYTES, s, p);
+      BL_CHECK_LAUNCH();
+      return BL_OK;
+    }
+  }
   if (!big) {
     p.tiles_m = (p.M + 127) / 128;
     p.tiles_n = (p.N + 127) / 128;
@@ -1209,6 +1236,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     BL_LAUNCH256(tail * S);
     hipLaunchKernelGGL((gemm_splitk_reduce_kernel<EPI>), dim3(tail * 32), dim3(512), 0, s, p);
   } else {
+    // (65 … 128 leftover tiles — Llama qkv at B = 16: 96 — as 256 × 128 half tiles instead of a quarter-filled fourth round
+    // was measured at −0.6 % end to end: the half tiles stage 3/4 of a full tile's bytes for half its FLOPs)
     if (tail != 0 && tail <= 64 && main_tiles > tail && !force) main_tiles = big_tiles - tail; else tail = 0;
     BL_LAUNCH256(main_tiles);
     if (tail) {

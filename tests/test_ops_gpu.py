@@ -141,7 +141,7 @@ def test_gemm_splitk_tail(dev, M, N, K, epi):
     close_bf16(out, out2.cpu().float(), "split-K vs 128-tail dispatch", min_exact=0.97)
 
 
-@pytest.mark.parametrize("N,K", [(4096, 1024), (1024, 2048)])
+@pytest.mark.parametrize("N,K", [(4096, 1024), (1024, 2048), (12288, 512)])   # 12288: 96 leftover tiles = a partial fourth round
 def test_gemm_rows_independent_of_batch(dev, N, K):
     """Batch invariance at op level: a row's output must be bit-identical whether it is computed alone (M = 288 → the
     128x128 kernel) or inside a 16x larger problem (the 256x256 pipelined kernel, whole rounds + 128-tile tail), for
@@ -156,6 +156,27 @@ def test_gemm_rows_independent_of_batch(dev, N, K):
         one = torch.empty(S, N, dtype=torch.bfloat16, device=dev)
         ops.gemm(A[b * S:(b + 1) * S], W, one, ops.EPI_NONE)
         assert torch.equal(one, big[b * S:(b + 1) * S]), f"sequence {b}"
+
+
+@pytest.mark.parametrize("T,N,K", [(261, 1024, 1024), (256, 1152, 4352), (256, 1024, 640)])
+def test_gemm_ring160_vit_shapes_and_batch_invariance(dev, T, N, K):
+    """The narrow ViT layers at 16 images (attn.proj / mlp.fc2 / patch embed: M = 16·T rows, N ≤ 1152) run as ONE round of
+    160 × 128 tiles on the ring-buffered kernel (gemm_tail_kernel stand-alone mode): vs the oracle with the fused
+    bias + LayerScale + residual epilogue, and bit-identical per image to the one-image call (mid kernels)."""
+    from bridgelang_amd import ops
+    Bn = 16
+    M = Bn * T
+    a, w, b = rand_bf16((M, K), 1), rand_bf16((N, K), 2, 0.05), rand_bf16((N,), 3, 0.1)
+    r, ls = rand_bf16((M, N), 4), rand_bf16((N,), 5, 0.3)
+    A, Bv, Rr, Ls, W = dv(a, dev), dv(b, dev), dv(r, dev), dv(ls, dev), pk(w, dev)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(A, W, out, ops.EPI_BIAS_RES, bias=Bv, scale=Ls, res=Rr)
+    sel = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M)])          # first / last rows (incl. the ragged last tile)
+    close_bf16(out[sel], P.rb(r[sel] + P.rb(R.linear(P, a[sel], w, b) * ls)), "ring160 BIAS_RES+LayerScale")
+    for img in (0, 9, 15):
+        one = torch.empty(T, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(A[img * T:(img + 1) * T], W, one, ops.EPI_BIAS_RES, bias=Bv, scale=Ls, res=Rr[img * T:(img + 1) * T])
+        assert torch.equal(one, out[img * T:(img + 1) * T]), f"image {img}: result depends on the batch it ran in"
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 192, 128), (522, 256, 1088), (1305, 768, 448)])
