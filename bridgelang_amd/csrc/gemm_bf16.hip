@@ -634,6 +634,160 @@ __global__ __launch_bounds__(256) void gemm_mid2_kernel(GemmArgs p) {
 }
 
 // ======================================================================================================================
+// 288 × 256 tile — one 288-token sequence (S = 1 + 256 + 31) per row tile.
+// At the bench shape M = 16 · 288 = 4608 the 256-row tiles come out as 18 row tiles: Llama o_proj / down_proj get 288 tiles
+// = one round + a 32-tile tail on sub-tiles at a third of the efficiency (+ 45 % time for 12.5 % of the work), qkv gets
+// 864 = 3.375 rounds (a quarter-filled fourth round). With 288 rows per tile the same GEMMs are exactly 256 tiles
+// (o / down) and 768 = 3 rounds (qkv): no tail, no partial round.
+// 8 waves as 2 (m) × 4 (n): a wave owns 144 rows × 64 columns = 9 × 4 accumulator tiles (144 VGPRs); per K-tile six
+// phases (row third t ∈ 0..2 × column half h ∈ 0..1, 12 MFMAs each, order (0,0) (0,1) (1,1) (1,0) (2,0) (2,1)) on two
+// fragment register sets per operand, so a phase's MFMAs run over the next phase's ds_reads. LDS: 2 stages × 72 KiB
+// (288 rows × 128 B + 4 KiB landing area for the dummy pieces + 32 KiB weights). A wave issues 9 LDS-DMA pieces per
+// K-tile (5 activation — 36 real ones over 8 waves, the 4 surplus ones hit a zero-record descriptor: no traffic — and
+// 4 weight) for K-tile t+1 during phases 6 (of t-1), 1, 2, 3 (of t); ONE `vmcnt(0)` + barrier per K-tile, at the end of
+// phase 5, two phases after the last issue: it publishes K-tile t+1 (first read in phase 6) and retires every read of
+// K-tile t-1's stage before phase 6 re-fills it. No other barrier: the two waves of a SIMD drift apart inside a
+// K-tile and overlap one's LDS reads / DMA issue with the other's MFMAs.
+// K order per output = every other kernel's (K-tile by K-tile, two 32-steps each): bit-identical results.
+// ======================================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm288_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 288, BN = 256;
+  constexpr int A_BYTES = BM * ROW_BYTES, DUMMY = A_BYTES, W_OFF = A_BYTES + 4096, STAGE = W_OFF + 32768;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 × STAGE
+  int tm, tn;
+  tile_coords(p, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int kt32 = p.K >> 5, nk = p.K / BK;
+
+  const unsigned a_bytes = (unsigned)min((long)p.M * p.lda * 2, 0xffffffffL);
+  const unsigned w_bytes = (unsigned)min((long)p.N * p.K * 2, 0xffffffffL);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0, 0x00020000);
+
+  // activation pieces (8 rows × 128 B): wave takes pieces wave, wave + 8, …, wave + 32; pieces ≥ 36 do not exist
+  const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
+  unsigned voffA[5];
+  int ldsA[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int pi = wave + 8 * j;
+    voffA[j] = (unsigned)(((long)(m0 + pi * 8 + prow) * p.lda) * 2 + pchunk * 16);
+    ldsA[j] = pi < 36 ? pi * 1024 : DUMMY + (pi - 36) * 1024;
+  }
+  const bool a4_real = wave < 4;                       // piece wave + 32 exists only for waves 0..3
+  // weight pieces: n-tiles 2·wave and 2·wave + 1, both k-steps (2 KiB contiguous per n-tile and K-tile)
+  unsigned voffW[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) voffW[q] = (unsigned)((long)(n0 / 16 + 2 * wave + q) * kt32 * 1024 + lane * 16);
+  const int ldsW = W_OFF + 2 * wave * 2048;
+
+#define ISSUE_A(J, TILE)                                                                                  \
+  do {                                                                                                    \
+    const int t__ = (TILE);                                                                               \
+    /* no branch here: control flow inside the K loop makes hipcc shuttle the accumulators between VGPRs and AGPRs   \
+       around every MFMA (measured 1.8x slower); the surplus fifth piece of waves 4..7 goes to a zero-record descriptor */ \
+    const __amdgpu_buffer_rsrc_t rs__ = (t__ < nk && ((J) < 4 || a4_real)) ? rsA : rsA0;                  \
+    BL_GLDS(rs__, smem + (t__ & 1) * STAGE + ldsA[J], voffA[J], t__ * 128);                               \
+  } while (0)
+#define ISSUE_W(Q, KS, TILE)                                                                              \
+  do {                                                                                                    \
+    const int t__ = (TILE);                                                                               \
+    const __amdgpu_buffer_rsrc_t rs__ = t__ < nk ? rsW : rsW0;                                            \
+    BL_GLDS(rs__, smem + (t__ & 1) * STAGE + ldsW + (Q) * 2048 + (KS) * 1024, voffW[Q] + (KS) * 1024, t__ * 2048); \
+  } while (0)
+
+  const int cb0 = (lg ^ (lane & 7)) << 4;                       // swizzled chunk of k-step 0; k-step 1 = cb0 ^ 64
+  const int offX = (wm * 144 + l15) * ROW_BYTES;                // + (3·t + i)·2048
+  const int offY = W_OFF + wn * 8192 + lane * 16;               // + (2·h + j)·2048 + ks·1024
+#define READ_X(DST, T3, SB)                                                                               \
+  _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                         \
+    DST[i * 2] = *(const bf16x8_t*)((SB) + offX + (3 * (T3) + i) * 2048 + cb0);                           \
+    DST[i * 2 + 1] = *(const bf16x8_t*)((SB) + offX + (3 * (T3) + i) * 2048 + (cb0 ^ 64));                \
+  }
+#define READ_Y(DST, NH, SB)                                                                               \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                         \
+    DST[j * 2] = *(const bf16x8_t*)((SB) + offY + (2 * (NH) + j) * 2048);                                 \
+    DST[j * 2 + 1] = *(const bf16x8_t*)((SB) + offY + (2 * (NH) + j) * 2048 + 1024);                      \
+  }
+#define MMA(XR, YR, T3, NH)                                                                               \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                     \
+          acc[2 * (NH) + j][3 * (T3) + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
+              YR[j * 2 + ks], XR[i * 2 + ks], acc[2 * (NH) + j][3 * (T3) + i], 0, 0, 0);                  \
+  } while (0)
+#define PHASE_SYNC()                                                                                      \
+  do {                                                                                                    \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                           \
+    __builtin_amdgcn_s_barrier();                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+  } while (0)
+  // one K-tile: XC holds row third 0 and YC column half 0 of stage SC (K-tile T) on entry; YO takes half 1 and both stay
+  // for the whole K-tile, the thirds alternate between XC and XO; phase 6 loads third 0 / half 0 of K-tile T+1 (stage SN)
+  // into XO / YC, so the next K-tile runs with the X sets swapped
+  // (measured and rejected on this loop: s_setprio(1) around the MFMAs −8 %; sched_group_barrier placement of reads / pieces
+  // −5 % and 8 spilled registers; a wave-uniform branch around the surplus piece −77 % — control flow inside the K loop makes
+  // hipcc shuttle the accumulators through AGPRs around every MFMA. The compiler's own interleave below is the fastest.)
+#define KTILE(XC, XO, YC, YO, SC, SN, T)                                                                  \
+  do {                                                                                                    \
+    ISSUE_A(2, (T) + 1); ISSUE_A(3, (T) + 1); READ_Y(YO, 1, SC);                 MMA(XC, YC, 0, 0);       \
+    ISSUE_A(4, (T) + 1); ISSUE_W(0, 0, (T) + 1); READ_X(XO, 1, SC);              MMA(XC, YO, 0, 1);       \
+    ISSUE_W(0, 1, (T) + 1); ISSUE_W(1, 0, (T) + 1); ISSUE_W(1, 1, (T) + 1);      MMA(XO, YO, 1, 1);       \
+    READ_X(XC, 2, SC);                                                           MMA(XO, YC, 1, 0);       \
+                                                                                 MMA(XC, YC, 2, 0);       \
+    PHASE_SYNC();                                                                                         \
+    ISSUE_A(0, (T) + 2); ISSUE_A(1, (T) + 2); READ_X(XO, 0, SN); READ_Y(YC, 0, SN); MMA(XC, YO, 2, 1);    \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+  } while (0)
+
+  f32x4_t acc[4][9];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  bf16x8_t Xa[6], Xb[6], Ya[4], Yb[4];
+  char* const S0 = smem;
+  char* const S1 = smem + STAGE;
+
+  // prologue: all of K-tile 0, then the first two activation pieces of K-tile 1 (what phase 6 of the previous tile issues)
+  ISSUE_A(0, 0); ISSUE_A(1, 0); ISSUE_A(2, 0); ISSUE_A(3, 0); ISSUE_A(4, 0);
+  ISSUE_W(0, 0, 0); ISSUE_W(0, 1, 0); ISSUE_W(1, 0, 0); ISSUE_W(1, 1, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  ISSUE_A(0, 1); ISSUE_A(1, 1);
+  READ_X(Xa, 0, S0);
+  READ_Y(Ya, 0, S0);
+  for (int t = 0; t < nk; t += 2) {        // nk is even (launcher: K % 128 == 0)
+    KTILE(Xa, Xb, Ya, Yb, S0, S1, t);
+    KTILE(Xb, Xa, Ya, Yb, S1, S0, t + 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the out-of-range issues past the last K-tile
+#undef ISSUE_A
+#undef ISSUE_W
+#undef READ_X
+#undef READ_Y
+#undef MMA
+#undef PHASE_SYNC
+#undef KTILE
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+      epilogue_store4<EPI>(p, m0 + wm * 144 + j * 16 + l15, n0 + wn * 64 + i * 16 + lg * 4, acc[i][j]);
+#endif
+}
+
+// ======================================================================================================================
 // 256 × 256 tile, half-tile LDS-DMA ring, 4 phases per K-tile
 // ======================================================================================================================
 template <int EPI>
@@ -1078,6 +1232,8 @@ int set_lds_attr() {
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm288_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 73728) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * ROW_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tail_kernel<EPI, 128, 128, 4>),
@@ -1205,6 +1361,23 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     }
     BL_CHECK_LAUNCH();
     return BL_OK;
+  }
+  // 288-row tiles (one 288-token sequence per row tile) where they remove the leftover round: estimated cost in units of
+  // one round of 256 × 256 tiles — 256-row tiling: full rounds + 0.45 for a ≤ 64-tile tail on sub-tiles, 1 for a larger
+  // partial round; 288-row tiling: rounds × 1.12 (12.5 % more MFMA work and 6 % more staging per tile).
+  static const bool no_288 = getenv("BL_GEMM_NO_288") != nullptr;      // A/B aid
+  if (!force && !no_288 && (p.K % 128) == 0) {
+    const int t256 = big_tiles, r256 = t256 % CUS;
+    const float cost256 = (float)(t256 / CUS) + (r256 == 0 ? 0.f : (r256 <= 64 && t256 > CUS) ? 0.45f : 1.0f);
+    const int bm288 = (p.M + 287) / 288, t288 = bm288 * bn;
+    const float cost288 = 1.12f * (float)((t288 + CUS - 1) / CUS);
+    if (cost288 < 0.97f * cost256) {
+      p.tiles_m = bm288;
+      p.tiles_n = bn;
+      hipLaunchKernelGGL((gemm288_kernel<EPI>), dim3(t288), dim3(512), 2 * 73728, s, p);
+      BL_CHECK_LAUNCH();
+      return BL_OK;
+    }
   }
   // Whole rounds of 256 tiles on the pipelined kernel; a partial last round would leave most CUs idle for a full tile
   // time, so its tiles are cut into 128x128 quarters and run by the small kernel (2 workgroups per CU) instead.

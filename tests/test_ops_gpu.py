@@ -158,6 +158,39 @@ def test_gemm_rows_independent_of_batch(dev, N, K):
         assert torch.equal(one, big[b * S:(b + 1) * S]), f"sequence {b}"
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(4608, 4096, 1024, "res"), (4591, 4000, 512, "none"), (4608, 12288, 256, "bias"),
+                                       (4608, 2048, 384, "swiglu")])
+def test_gemm288_sequence_tiles(dev, M, N, K, epi):
+    """288-row tiles (one 288-token sequence per row tile: gemm288_kernel) where they remove the leftover round of 256-row
+    tiling — Llama o_proj / down_proj / qkv at 16 × 288 rows — incl. ragged M and N and every epilogue family, against the
+    oracle on sampled rows and bit-identical to the 256-row tiling (BL_GEMM_NO_288 is read once per process, so the
+    comparison is against the per-sequence call, which takes the mid kernels)."""
+    from bridgelang_amd import ops
+    a, w, b, r = rand_bf16((M, K), 1), rand_bf16((N, K), 2, 0.05), rand_bf16((N,), 3, 0.1), rand_bf16((M, N), 4)
+    A, Bv, Rr = dv(a, dev), dv(b, dev), dv(r, dev)
+    sel = torch.cat([torch.arange(0, 200), torch.arange(2200, 2400), torch.arange(M - 200, M)])
+    if epi == "swiglu":
+        I = N // 2
+        W = pk(torch.stack([w[:I], w[I:]], 1).reshape(N, K), dev)
+        out = torch.empty(M, I, dtype=torch.bfloat16, device=dev)
+        kw, e = {}, ops.EPI_SWIGLU
+        g, u = R.linear(P, a[sel], w[:I]), R.linear(P, a[sel], w[I:])
+        ref = P.rb(P.rb(torch.nn.functional.silu(g)) * u)
+    else:
+        W = pk(w, dev)
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        kw, e = {"res": dict(res=Rr), "bias": dict(bias=Bv), "none": {}}[epi], {"res": ops.EPI_RES, "bias": ops.EPI_BIAS, "none": ops.EPI_NONE}[epi]
+        ref = {"res": lambda: P.rb(r[sel] + R.linear(P, a[sel], w)), "bias": lambda: R.linear(P, a[sel], w, b),
+               "none": lambda: R.linear(P, a[sel], w)}[epi]()
+    ops.gemm(A, W, out, e, **kw)
+    close_bf16(out[sel], ref, f"gemm288 {epi}")
+    for s0 in (0, 288 * 7, M - 288 - (M % 288 and 5)):              # one 288-row sequence at a time: the mid kernels
+        one = torch.empty(288, out.shape[1], dtype=torch.bfloat16, device=dev)
+        kw1 = {k: (v[s0:s0 + 288] if k == "res" else v) for k, v in kw.items()}
+        ops.gemm(A[s0:s0 + 288], W, one, e, **kw1)
+        assert torch.equal(one, out[s0:s0 + 288]), f"rows {s0}..: result depends on the tiling"
+
+
 @pytest.mark.parametrize("T,N,K", [(261, 1024, 1024), (256, 1152, 4352), (256, 1024, 640)])
 def test_gemm_ring160_vit_shapes_and_batch_invariance(dev, T, N, K):
     """The narrow ViT layers at 16 images (attn.proj / mlp.fc2 / patch embed: M = 16·T rows, N ≤ 1152) run as ONE round of
