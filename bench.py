@@ -295,8 +295,8 @@ def train_main(args, rank: int, world: int, dev, distributed: bool) -> None:
         torch.cuda.synchronize()
         agg: dict = {}
         for i, op in enumerate(plan):
-            a = agg.setdefault(op.name, {"launches": 0, "ms": 0.0, "flops": 0.0})
-            a["launches"] += 1; a["ms"] += evs[i].elapsed_time(evs[i + 1]); a["flops"] += op.flops
+            a = agg.setdefault(op.name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            a["launches"] += 1; a["ms"] += evs[i].elapsed_time(evs[i + 1]); a["flops"] += op.flops; a["bytes"] += op.bytes
         gemm = agg["bl_gemm_bf16"]
         achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
         model_flops = sum(op.flops for op in plan)
@@ -323,6 +323,8 @@ def train_main(args, rank: int, world: int, dev, distributed: bool) -> None:
                            "mfma_util_whole_step": round(model_flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
                            "phases_ms_eager_events": phases,
                            "per_kernel_ms": {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
+                           "hbm_bound_kernels_GBs": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9) for k, v in
+                                                     sorted(agg.items(), key=lambda kv: -kv[1]["ms"]) if v["bytes"] and not v["flops"]},
                            "trainable_params_B": round(ts.store.n_params / 1e9, 3),
                            "hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                            "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)]},

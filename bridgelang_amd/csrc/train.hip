@@ -70,11 +70,20 @@ __global__ __launch_bounds__(256) void ce_backward_kernel(const float* logits, l
 //   RMS: g = w ⊙ dy;  x̂ = x·rstd;        dx = rstd·(g − x̂·mean(g ⊙ x̂)) [+ dres];          dw = Σ_rows dy ⊙ bf16(x̂)
 //   LN : g = w ⊙ dy;  x̂ = (x − μ)·rstd;  dx = rstd·(g − mean(g) − x̂·mean(g ⊙ x̂)) [+ dres]; dw = Σ dy ⊙ x̂;  db = Σ dy
 // Per-block partials of dw (and db, stored behind the dw partials) are summed by reduce_partials_kernel.
+// RPW rows per wave are in flight together (their loads are issued back to back and the wave-wide reductions of the rows
+// interleave): one row per wave left a single 2·dim-byte request outstanding and ran at 0.7 TB/s (LayerNorm, dim ≈ 1 K) /
+// 1.7 TB/s (RMSNorm, dim 4 K). x and dy stay PACKED in registers (4 VGPRs per 8 values) and are unpacked in each pass.
+template <int NCH> constexpr int norm_bwd_rpw() { return NCH <= 3 ? 4 : NCH <= 4 ? 2 : 1; }
+
 template <int NCH, bool LN>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(const uint16_t* x, long ldx, const uint16_t* w,
                                                        const uint16_t* dy, long lddy, const uint16_t* dres,
                                                        long lddres, uint16_t* dx, long lddx, float* dw_partial,
                                                        int rows, int dim, float eps, int rows_per_block) {
+  constexpr int RPW = norm_bwd_rpw<NCH>();
+  // the packed registers are re-read through an empty asm before each pass: otherwise hipcc keeps every unpacked float of
+  // every row alive across the passes (256 VGPRs + 250 AGPRs, one wave per SIMD)
+#define BL_FRESH(Q) asm volatile("" : "+v"(Q))
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = dim >> 3;
   const float inv_dim = 1.0f / (float)dim;
@@ -83,70 +92,96 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const uint16_t* x, long l
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
     for (int i = 0; i < 8; ++i) { dwacc[c][i] = 0.f; if (LN) dbacc[c][i] = 0.f; }
-  const int r0 = blockIdx.x * rows_per_block;
-  for (int rr = wave; rr < rows_per_block; rr += 4) {
-    const int row = r0 + rr;
-    if (row >= rows) break;
-    float xv[NCH][8], dyv[NCH][8];
-    float sx = 0.f;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (int rr = r0 + wave * RPW; rr < r1; rr += 4 * RPW) {
+    u32x4_t qx[RPW][NCH], qd[RPW][NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int ch = c * 64 + lane;
-      u32x4_t qx = {0u, 0u, 0u, 0u}, qd = qx;
-      if (ch < nchunk) {
-        qx = *(const u32x4_t*)(x + (long)row * ldx + ch * 8);
-        qd = *(const u32x4_t*)(dy + (long)row * lddy + ch * 8);
+    for (int u = 0; u < RPW; ++u)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = c * 64 + lane, row = rr + u;
+        qx[u][c] = qd[u][c] = (u32x4_t){0u, 0u, 0u, 0u};      // rows past the block / columns past dim contribute zeros
+        if (ch < nchunk && row < r1) {
+          qx[u][c] = *(const u32x4_t*)(x + (long)row * ldx + ch * 8);
+          qd[u][c] = *(const u32x4_t*)(dy + (long)row * lddy + ch * 8);
+        }
       }
-      unpack8(qx, xv[c]); unpack8(qd, dyv[c]);
+    float mu[RPW], rstd[RPW], dot[RPW], gsum[RPW];
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+      mu[u] = 0.f;
       if (LN) {
+        float sx = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sx += xv[c][i];
+        for (int c = 0; c < NCH; ++c) {
+          float v[8];
+          BL_FRESH(qx[u][c]);
+          unpack8(qx[u][c], v);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) sx += v[i];
+        }
+        mu[u] = wave_sum(sx) * inv_dim;
       }
     }
-    float mu = 0.f;
-    if (LN) mu = wave_sum(sx) * inv_dim;
-    float ss = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const bool in = c * 64 + lane < nchunk;
+    for (int u = 0; u < RPW; ++u) {
+      float ss = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (LN) xv[c][i] = in ? xv[c][i] - mu : 0.f;
-        ss += xv[c][i] * xv[c][i];
+      for (int c = 0; c < NCH; ++c) {
+        const bool in = c * 64 + lane < nchunk;
+        float v[8];
+        BL_FRESH(qx[u][c]);
+        unpack8(qx[u][c], v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float xc = (LN && in) ? v[i] - mu[u] : (LN ? 0.f : v[i]);
+          ss += xc * xc;
+        }
       }
+      rstd[u] = 1.0f / sqrtf(wave_sum(ss) * inv_dim + eps);
     }
-    ss = wave_sum(ss);
-    const float rstd = 1.0f / sqrtf(ss * inv_dim + eps);
-    float dot = 0.f, gsum = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int ch = c * 64 + lane;
-      float wv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (ch < nchunk) unpack8(*(const u32x4_t*)(w + ch * 8), wv);
+    for (int u = 0; u < RPW; ++u) {
+      float d = 0.f, g1 = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float g = wv[i] * dyv[c][i];
-        dot += g * xv[c][i] * rstd;
-        if (LN) gsum += g;
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = c * 64 + lane;
+        float wv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, xv[8], dv[8];
+        if (ch < nchunk) unpack8(*(const u32x4_t*)(w + ch * 8), wv);
+        BL_FRESH(qx[u][c]); BL_FRESH(qd[u][c]);
+        unpack8(qx[u][c], xv); unpack8(qd[u][c], dv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float g = wv[i] * dv[i];
+          const float xc = (LN && ch < nchunk) ? xv[i] - mu[u] : (LN ? 0.f : xv[i]);
+          d += g * xc * rstd[u];
+          if (LN) g1 += g;
+        }
       }
+      dot[u] = wave_sum(d) * inv_dim;
+      gsum[u] = LN ? wave_sum(g1) * inv_dim : 0.f;
     }
-    dot = wave_sum(dot) * inv_dim;
-    if (LN) gsum = wave_sum(gsum) * inv_dim;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int ch = c * 64 + lane;
-      if (ch >= nchunk) continue;
-      float o[8], dr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wv[8];
-      unpack8(*(const u32x4_t*)(w + ch * 8), wv);
-      if (dres) unpack8(*(const u32x4_t*)(dres + (long)row * lddres + ch * 8), dr);
+    for (int u = 0; u < RPW; ++u) {
+      const int row = rr + u;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float xh = xv[c][i] * rstd;
-        o[i] = rstd * (wv[i] * dyv[c][i] - gsum - xh * dot) + dr[i];
-        dwacc[c][i] += dyv[c][i] * (LN ? xh : rbf(xh));
-        if (LN) dbacc[c][i] += dyv[c][i];
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch >= nchunk || row >= r1) continue;
+        float o[8], dr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wv[8], xv[8], dv[8];
+        unpack8(*(const u32x4_t*)(w + ch * 8), wv);
+        BL_FRESH(qx[u][c]); BL_FRESH(qd[u][c]);
+        unpack8(qx[u][c], xv); unpack8(qd[u][c], dv);
+        if (dres) unpack8(*(const u32x4_t*)(dres + (long)row * lddres + ch * 8), dr);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float xh = (LN ? xv[i] - mu[u] : xv[i]) * rstd[u];
+          o[i] = rstd[u] * (wv[i] * dv[i] - gsum[u] - xh * dot[u]) + dr[i];
+          dwacc[c][i] += dv[i] * (LN ? xh : rbf(xh));
+          if (LN) dbacc[c][i] += dv[i];
+        }
+        *(u32x4_t*)(dx + (long)row * lddx + ch * 8) = pack8(o);
       }
-      *(u32x4_t*)(dx + (long)row * lddx + ch * 8) = pack8(o);
     }
   }
   // per-block partials: the 4 waves of the block own disjoint rows → sum them through LDS, lane-major
@@ -170,6 +205,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const uint16_t* x, long l
       __syncthreads();
     }
   }
+#undef BL_FRESH
 }
 
 // out[j] = Σ_b partial[b][j]   (fixed order → deterministic). Block = 64 columns × 4 row groups.
@@ -177,29 +213,57 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* parti
   __shared__ float sh[4][64];
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + c;
-  float s = 0.f;
-  if (j < dim)
-    for (int b = rg; b < nblocks; b += 4) s += partial[(long)b * dim + j];
+  // eight independent partial sums per thread (fixed assignment → still deterministic): the single dependent chain of
+  // the first version (130+ serial loads per thread on 16–64 blocks) cost more than the norm backward pass it finished
+  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (j < dim) {
+    int b = rg;
+    for (; b + 28 < nblocks; b += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s8[u] += partial[(long)(b + 4 * u) * dim + j];
+    }
+    for (int u = 0; b < nblocks; b += 4, ++u) s8[u] += partial[(long)b * dim + j];
+  }
+  const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   sh[rg][c] = s;
   __syncthreads();
   if (rg == 0 && j < dim) out[j] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
 }
 
-// column sums of a bf16 matrix [rows, cols] → per-block partials (bias gradients)
+// column sums of a bf16 matrix [rows, cols] → per-block partials (bias gradients). Block = 64 column chunks (512
+// columns, one contiguous KiB per row for a wave) × 4 row groups; every thread keeps four independent row loads in flight
+// (the first version walked its rows one dependent load at a time: 0.8 TB/s); the row groups are summed through LDS.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const uint16_t* a, long lda, int rows, int cols,
                                                              int rows_per_block, float* partial) {
-  const int col8 = (blockIdx.y * 256 + threadIdx.x) * 8;
-  if (col8 >= cols) return;
+  __shared__ float sh[4][64 * 8];
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col8 = (blockIdx.y * 64 + lane) * 8;
+  const bool live = col8 < cols;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  for (int r = r0; r < r1; ++r) {
-    float v[8];
-    unpack8(*(const u32x4_t*)(a + (long)r * lda + col8), v);
+  for (int r = r0 + rg; r < r1; r += 16) {
+    u32x4_t q[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] += v[i];
+    for (int u = 0; u < 4; ++u) {
+      q[u] = (u32x4_t){0u, 0u, 0u, 0u};
+      if (live && r + 4 * u < r1) q[u] = *(const u32x4_t*)(a + (long)(r + 4 * u) * lda + col8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float v[8];
+      unpack8(q[u], v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += v[i];
+    }
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) partial[(long)blockIdx.x * cols + col8 + i] = acc[i];
+  for (int i = 0; i < 8; ++i) sh[rg][lane * 8 + i] = acc[i];
+  __syncthreads();
+  if (rg == 0 && live) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      partial[(long)blockIdx.x * cols + col8 + i] = (sh[0][lane * 8 + i] + sh[1][lane * 8 + i]) + (sh[2][lane * 8 + i] + sh[3][lane * 8 + i]);
+  }
 }
 
 // ---- SwiGLU on an interleaved gate/up buffer gu [M, 2I] (col 2j = gate_j, 2j+1 = up_j) ----
@@ -431,7 +495,9 @@ __global__ __launch_bounds__(256) void transpose_fast_kernel(const uint16_t* in,
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(16))) char tile[256 * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int r0 = blockIdx.x * 256, c0 = blockIdx.y * 64;
+  // column tiles vary fastest over the grid: workgroups running together read neighbouring 128-byte segments of the
+  // same rows (whole DRAM bursts / pages) instead of isolated segments 256 rows apart
+  const int r0 = blockIdx.y * 256, c0 = blockIdx.x * 64;
   u32x4_t v[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
@@ -808,15 +874,15 @@ extern "C" int bl_colsum_bf16(const bl_bf16* a, int64_t lda, int32_t rows, int32
                               int64_t partial_ws_floats, void* stream) {
   if (!a || !out || !partial_ws) return BL_E_ARG;
   if (rows <= 0 || cols <= 0 || (cols % 8) || (lda % 8)) return BL_E_SHAPE;
-  // rows per block: as few as the workspace allows (>= 16) so the grid covers the chip even for narrow matrices
-  int rpb = 16;
+  // rows per block: as few as the workspace allows (>= 64: 16 rows per row group) so the grid covers the chip
+  int rpb = 64;
   while ((int64_t)((rows + rpb - 1) / rpb) * cols > partial_ws_floats) {
     rpb *= 2;
     if (rpb > (1 << 20)) return BL_E_SHAPE;
   }
   const int nblk = (rows + rpb - 1) / rpb;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, (cols / 8 + 255) / 256), dim3(256), 0, s, a, (long)lda, rows, cols,
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, (cols / 8 + 63) / 64), dim3(256), 0, s, a, (long)lda, rows, cols,
                      rpb, partial_ws);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial_ws, nblk, cols, out);
   BL_CHECK_LAUNCH();
@@ -887,7 +953,7 @@ extern "C" int bl_transpose_pad_bf16(const bl_bf16* in, int64_t ldi, int32_t row
   if (!in || !out) return BL_E_ARG;
   if (rows <= 0 || cols <= 0 || rows_pad < rows || ldo < rows_pad) return BL_E_SHAPE;
   if ((cols % 64) == 0 && (rows_pad % 32) == 0 && (ldi % 8) == 0 && (ldo % 8) == 0 && bl_aligned16(in) && bl_aligned16(out))
-    hipLaunchKernelGGL((transpose_fast_kernel<false>), dim3((rows_pad + 255) / 256, cols / 64), dim3(256), 0,
+    hipLaunchKernelGGL((transpose_fast_kernel<false>), dim3(cols / 64, (rows_pad + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, in, (long)ldi, rows, cols, out, (long)ldo, rows_pad, 0L, 0L);
   else
     hipLaunchKernelGGL(transpose_pad_kernel, dim3((rows_pad + 63) / 64, (cols + 63) / 64), dim3(256), 0, (hipStream_t)stream,
@@ -901,7 +967,7 @@ extern "C" int bl_transpose_pack_bf16(const bl_bf16* in, int64_t ldi, int32_t ro
   if (!in || !out_packed) return BL_E_ARG;
   if (rows <= 0 || cols <= 0 || rows_pad < rows || (cols % 64) || (rows_pad % 32) || (ldi % 8)) return BL_E_SHAPE;
   if (!bl_aligned16(in) || !bl_aligned16(out_packed)) return BL_E_ALIGN;
-  hipLaunchKernelGGL((transpose_fast_kernel<true>), dim3((rows_pad + 255) / 256, cols / 64), dim3(256), 0,
+  hipLaunchKernelGGL((transpose_fast_kernel<true>), dim3(cols / 64, (rows_pad + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, in, (long)ldi, rows, cols, out_packed, 0L, rows_pad, (long)(rows_pad / 32), 0L);
   BL_CHECK_LAUNCH();
   return BL_OK;
@@ -914,7 +980,7 @@ extern "C" int bl_transpose_pack_into_bf16(const bl_bf16* in, int64_t ldi, int32
       kb_offset + rows_pad / 32 > kt_total)
     return BL_E_SHAPE;
   if (!bl_aligned16(in) || !bl_aligned16(out_packed)) return BL_E_ALIGN;
-  hipLaunchKernelGGL((transpose_fast_kernel<true>), dim3((rows_pad + 255) / 256, cols / 64), dim3(256), 0,
+  hipLaunchKernelGGL((transpose_fast_kernel<true>), dim3(cols / 64, (rows_pad + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, in, (long)ldi, rows, cols, out_packed, 0L, rows_pad, (long)kt_total, (long)kb_offset);
   BL_CHECK_LAUNCH();
   return BL_OK;
