@@ -788,6 +788,177 @@ __global__ __launch_bounds__(512) void gemm288_kernel(GemmArgs p) {
 }
 
 // ======================================================================================================================
+// 288 × 256 tile, staggered wave groups (the structure of gemm256s_kernel on the 288-row tile): the two 4-wave groups that
+// share each SIMD alternate roles segment by segment — one runs a 12-MFMA block while the other issues its LDS-DMA pieces
+// and reads the fragments of its next block — with one raw s_barrier per segment. A single X register set suffices (a
+// group's fragment reads happen while its MFMAs are not running): 9 × 4 accumulator tiles (144 VGPRs) + 6 + 4 + 4 fragments.
+// K-tile T+1's nine pieces per wave are issued over the six slots p6(T-1), p1 … p5(T) (2, 1, 2, 1, 2, 1); slot p6(T) issues
+// the first two pieces of T+2 and waits `vmcnt(2)`: everything older — all of T+1 — has landed, two barriers before its
+// first read (slot p1 of T+1), and the DMA stream never drains. Stage T is re-filled from slot p6(T) on; its last reads
+// are in slot p5(T) of either group, one barrier earlier.
+// ======================================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm288s_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 288, BN = 256;
+  constexpr int A_BYTES = BM * ROW_BYTES, DUMMY = A_BYTES, W_OFF = A_BYTES + 4096, STAGE = W_OFF + 32768;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 × STAGE
+  int tm, tn;
+  tile_coords(p, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int kt32 = p.K >> 5, nk = p.K / BK;
+
+  const unsigned a_bytes = (unsigned)min((long)p.M * p.lda * 2, 0xffffffffL);
+  const unsigned w_bytes = (unsigned)min((long)p.N * p.K * 2, 0xffffffffL);
+  const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
+  unsigned voffA[5];
+  int ldsA[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int pi = wave + 8 * j;
+    voffA[j] = (unsigned)(((long)(m0 + pi * 8 + prow) * p.lda) * 2 + pchunk * 16);
+    ldsA[j] = pi < 36 ? pi * 1024 : DUMMY + (pi - 36) * 1024;
+  }
+  const unsigned a4_bytes = wave < 4 ? a_bytes : 0u;      // piece wave + 32 exists for waves 0..3 only (zero-size descriptor)
+  unsigned voffW[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) voffW[q] = (unsigned)((long)(n0 / 16 + 2 * wave + q) * kt32 * 1024 + lane * 16);
+  const int ldsW = W_OFF + 2 * wave * 2048;
+#define BL_RS(PTR, BYTES) __builtin_amdgcn_make_buffer_rsrc((void*)(PTR), 0, (BYTES), 0x00020000)
+#define ISSUE_A(J, TILE)                                                                                  \
+  do {                                                                                                    \
+    const int t__ = (TILE);                                                                               \
+    const __amdgpu_buffer_rsrc_t rs__ = BL_RS(p.A, t__ < nk ? ((J) < 4 ? a_bytes : a4_bytes) : 0u);       \
+    BL_GLDS(rs__, smem + (t__ & 1) * STAGE + ldsA[J], voffA[J], t__ * 128);                               \
+  } while (0)
+#define ISSUE_W(Q, KS, TILE)                                                                              \
+  do {                                                                                                    \
+    const int t__ = (TILE);                                                                               \
+    const __amdgpu_buffer_rsrc_t rs__ = BL_RS(p.W, t__ < nk ? w_bytes : 0u);                              \
+    BL_GLDS(rs__, smem + (t__ & 1) * STAGE + ldsW + (Q) * 2048 + (KS) * 1024, voffW[Q] + (KS) * 1024, t__ * 2048); \
+  } while (0)
+  const int cb0 = (lg ^ (lane & 7)) << 4;
+  const int offX = (wm * 144 + l15) * ROW_BYTES;
+  const int offY = W_OFF + wn * 8192 + lane * 16;
+#define READ_X(T3, SB)                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                         \
+    X[i * 2] = *(const bf16x8_t*)((SB) + offX + (3 * (T3) + i) * 2048 + cb0);                             \
+    X[i * 2 + 1] = *(const bf16x8_t*)((SB) + offX + (3 * (T3) + i) * 2048 + (cb0 ^ 64));                  \
+  }
+#define READ_Y(DST, NH, SB)                                                                               \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                         \
+    DST[j * 2] = *(const bf16x8_t*)((SB) + offY + (2 * (NH) + j) * 2048);                                 \
+    DST[j * 2 + 1] = *(const bf16x8_t*)((SB) + offY + (2 * (NH) + j) * 2048 + 1024);                      \
+  }
+#define MMA(YR, T3, NH)                                                                                   \
+  do {                                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                     \
+          acc[2 * (NH) + j][3 * (T3) + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
+              YR[j * 2 + ks], X[i * 2 + ks], acc[2 * (NH) + j][3 * (T3) + i], 0, 0, 0);                   \
+    __builtin_amdgcn_s_setprio(0);                                                                        \
+  } while (0)
+#define BAR()                                                                                             \
+  do {                                                                                                    \
+    __builtin_amdgcn_s_barrier();                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+  } while (0)
+#define WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define WAIT_VM2_LGKM() asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory")
+  // the six slots of K-tile T (stage SC; SN = the other stage): fragment reads first, then the LDS-DMA issue
+#define SLOT1(SC, T) do { READ_X(0, SC); READ_Y(Ya, 0, SC); __builtin_amdgcn_sched_barrier(0); ISSUE_A(2, (T) + 1); WAIT_LGKM(); } while (0)
+#define SLOT2(SC, T) do { READ_Y(Yb, 1, SC); __builtin_amdgcn_sched_barrier(0); ISSUE_A(3, (T) + 1); ISSUE_A(4, (T) + 1); WAIT_LGKM(); } while (0)
+#define SLOT3(SC, T) do { READ_X(1, SC); __builtin_amdgcn_sched_barrier(0); ISSUE_W(0, 0, (T) + 1); WAIT_LGKM(); } while (0)
+#define SLOT4(SC, T) do { ISSUE_W(0, 1, (T) + 1); ISSUE_W(1, 0, (T) + 1); } while (0)
+#define SLOT5(SC, T) do { READ_X(2, SC); __builtin_amdgcn_sched_barrier(0); ISSUE_W(1, 1, (T) + 1); WAIT_LGKM(); } while (0)
+#define SLOT6(SC, T) do { ISSUE_A(0, (T) + 2); ISSUE_A(1, (T) + 2); WAIT_VM2_LGKM(); } while (0)
+#define BL_EPILOGUE()                                                                                     \
+  do {                                                                                                    \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+      _Pragma("unroll") for (int j = 0; j < 9; ++j)                                                       \
+        epilogue_store4<EPI>(p, m0 + wm * 144 + j * 16 + l15, n0 + wn * 64 + i * 16 + lg * 4, acc[i][j]); \
+  } while (0)
+
+  f32x4_t acc[4][9];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  bf16x8_t X[6], Ya[4], Yb[4];
+  char* const S0 = smem;
+  char* const S1 = smem + STAGE;
+
+  // prologue: all nine pieces of K-tile 0, then what slot p6 of "K-tile -1" issues (the first two pieces of K-tile 1)
+  ISSUE_A(0, 0); ISSUE_A(1, 0); ISSUE_A(2, 0); ISSUE_A(3, 0); ISSUE_A(4, 0);
+  ISSUE_W(0, 0, 0); ISSUE_W(0, 1, 0); ISSUE_W(1, 0, 0); ISSUE_W(1, 1, 0);
+  ISSUE_A(0, 1); ISSUE_A(1, 1);
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  BAR();
+  if (wm == 0) {
+    // ======================= group A: MFMA block first, then the slot of the NEXT block =======================
+    SLOT1(S0, 0);
+    BAR();
+    for (int t = 0; t < nk; t += 2) {        // nk is even (launcher: K % 128 == 0)
+      MMA(Ya, 0, 0); BAR();   SLOT2(S0, t); BAR();
+      MMA(Yb, 0, 1); BAR();   SLOT3(S0, t); BAR();
+      MMA(Yb, 1, 1); BAR();   SLOT4(S0, t); BAR();
+      MMA(Ya, 1, 0); BAR();   SLOT5(S0, t); BAR();
+      MMA(Ya, 2, 0); BAR();   SLOT6(S0, t); BAR();
+      MMA(Yb, 2, 1); BAR();   SLOT1(S1, t + 1); BAR();
+      MMA(Ya, 0, 0); BAR();   SLOT2(S1, t + 1); BAR();
+      MMA(Yb, 0, 1); BAR();   SLOT3(S1, t + 1); BAR();
+      MMA(Yb, 1, 1); BAR();   SLOT4(S1, t + 1); BAR();
+      MMA(Ya, 1, 0); BAR();   SLOT5(S1, t + 1); BAR();
+      MMA(Ya, 2, 0); BAR();   SLOT6(S1, t + 1); BAR();
+      MMA(Yb, 2, 1); BAR();   SLOT1(S0, t + 2); BAR();
+    }
+    BL_EPILOGUE();
+    return;
+  }
+  // ========================= group B: the slot of THIS block first, then its MFMA block =========================
+  BAR();
+  for (int t = 0; t < nk; t += 2) {
+    SLOT1(S0, t); BAR();       MMA(Ya, 0, 0); BAR();
+    SLOT2(S0, t); BAR();       MMA(Yb, 0, 1); BAR();
+    SLOT3(S0, t); BAR();       MMA(Yb, 1, 1); BAR();
+    SLOT4(S0, t); BAR();       MMA(Ya, 1, 0); BAR();
+    SLOT5(S0, t); BAR();       MMA(Ya, 2, 0); BAR();
+    SLOT6(S0, t); BAR();       MMA(Yb, 2, 1); BAR();
+    SLOT1(S1, t + 1); BAR();   MMA(Ya, 0, 0); BAR();
+    SLOT2(S1, t + 1); BAR();   MMA(Yb, 0, 1); BAR();
+    SLOT3(S1, t + 1); BAR();   MMA(Yb, 1, 1); BAR();
+    SLOT4(S1, t + 1); BAR();   MMA(Ya, 1, 0); BAR();
+    SLOT5(S1, t + 1); BAR();   MMA(Ya, 2, 0); BAR();
+    SLOT6(S1, t + 1); BAR();   MMA(Yb, 2, 1); BAR();
+  }
+  BL_EPILOGUE();
+#undef BL_RS
+#undef ISSUE_A
+#undef ISSUE_W
+#undef READ_X
+#undef READ_Y
+#undef MMA
+#undef BAR
+#undef WAIT_LGKM
+#undef WAIT_VM2_LGKM
+#undef SLOT1
+#undef SLOT2
+#undef SLOT3
+#undef SLOT4
+#undef SLOT5
+#undef SLOT6
+#undef BL_EPILOGUE
+#endif
+}
+
+// ======================================================================================================================
 // 256 × 256 tile, half-tile LDS-DMA ring, 4 phases per K-tile
 // ======================================================================================================================
 template <int EPI>
@@ -1234,6 +1405,8 @@ int set_lds_attr() {
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm288_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 73728) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm288s_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 73728) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * ROW_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tail_kernel<EPI, 128, 128, 4>),
@@ -1374,7 +1547,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (cost288 < 0.97f * cost256) {
       p.tiles_m = bm288;
       p.tiles_n = bn;
-      hipLaunchKernelGGL((gemm288_kernel<EPI>), dim3(t288), dim3(512), 2 * 73728, s, p);
+      static const bool lockstep288 = getenv("BL_GEMM_288_LOCKSTEP") != nullptr;      // A/B aid
+      if (lockstep288) hipLaunchKernelGGL((gemm288_kernel<EPI>), dim3(t288), dim3(512), 2 * 73728, s, p);
+      else hipLaunchKernelGGL((gemm288s_kernel<EPI>), dim3(t288), dim3(512), 2 * 73728, s, p);
       BL_CHECK_LAUNCH();
       return BL_OK;
     }
