@@ -1226,35 +1226,22 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
               YR[j * 2 + ks], XR[i * 2 + ks], acc[2 * (NH) + j][4 * (MH) + i], 0, 0, 0);                \
     __builtin_amdgcn_s_setprio(0);                                                                      \
   } while (0)
-#if defined(BL_EXP_NOBAR)   /* timing experiment only (results invalid): how much of the loop is barrier cost */
-#define BAR() __builtin_amdgcn_sched_barrier(0)
-#else
+// (the timing-only variants of these four macros — no barrier / no wait / no issue / no reads — are generated into a
+//  patched copy of this file by tools/micro/gemm_loop_experiments.py; nothing here is conditional)
 #define BAR()                                   \
   do {                                          \
     __builtin_amdgcn_s_barrier();               \
     __builtin_amdgcn_sched_barrier(0);          \
   } while (0)
-#endif
-#if defined(BL_EXP_NOWAIT)   /* timing experiment only (results invalid): loop time without waiting for the LDS-DMA */
-#define WAIT_VM8() asm volatile("" ::: "memory")
-#define WAIT_VM10_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#else
 #define WAIT_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #define WAIT_VM10_LGKM() asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory")
-#endif
 #define WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
   // H(p+6) for phase q of K-tile T:  q=0 → X1(T+1)   q=1 → Y0(T+2)   q=2 → X0(T+2)   q=3 → Y1(T+2)
 // the fragment reads go first, the LDS-DMA issue second: the ≈ 80 cycles each piece takes to issue cover the reads' latency
 // instead of preceding it (+1.5–2.3 % on every shape, same box A/B). Tried and rejected: moving one of the two pieces between
 // the two k-steps of the wave's next MFMA segment (to thin out the burst of 8 pieces per segment): −3 %, the piece's issue
 // time then stalls the MFMA stream itself.
-#if defined(BL_EXP_NO_ISSUE)     /* timing experiments only (results invalid): segment cost without the LDS-DMA issue / the reads */
-#define ISSUE_READ(I, R) do { R; } while (0)
-#elif defined(BL_EXP_NO_READ)
-#define ISSUE_READ(I, R) do { I; } while (0)
-#else
 #define ISSUE_READ(I, R) do { R; __builtin_amdgcn_sched_barrier(0); I; } while (0)
-#endif
 #define ISSUE_Q0(T) ISSUE_X(1, (T) + 1)
 #define ISSUE_Q1(T) ISSUE_Y(0, (T) + 2)
 #define ISSUE_Q2(T) ISSUE_X(0, (T) + 2)

@@ -129,22 +129,13 @@ __global__ __launch_bounds__(512) void gemm256s_fp8_kernel(GemmArgs p) {
             YR[j], XR[i], acc[2 * (NH) + j][4 * (MH) + i], 0, 0, 0, ONE_E8M0, 0, ONE_E8M0);             \
     __builtin_amdgcn_s_setprio(0);                                                                      \
   } while (0)
-#if defined(BL_EXP_NOBAR)   /* timing experiment only (results invalid): how much of the loop is barrier cost */
-#define BAR() __builtin_amdgcn_sched_barrier(0)
-#else
 #define BAR()                                   \
   do {                                          \
     __builtin_amdgcn_s_barrier();               \
     __builtin_amdgcn_sched_barrier(0);          \
   } while (0)
-#endif
-#if defined(BL_EXP_NOWAIT)   /* timing experiment only (results invalid): loop time without waiting for the LDS-DMA */
-#define WAIT_VM8() asm volatile("" ::: "memory")
-#define WAIT_VM10_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#else
 #define WAIT_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #define WAIT_VM10_LGKM() asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory")
-#endif
 #define WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
   // H(p+6) for phase q of K-tile T:  q=0 → X1(T+1)   q=1 → Y0(T+2)   q=2 → X0(T+2)   q=3 → Y1(T+2)
 #define ISSUE_READ(I, R) do { R; __builtin_amdgcn_sched_barrier(0); I; } while (0)   // reads first (gemm_bf16.hip)

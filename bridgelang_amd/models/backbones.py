@@ -114,7 +114,8 @@ class LLaMa2LLMBackbone(LLMBackbone):
         return 32000
 
     def enable_gradient_checkpointing(self) -> None:
-        """No-op: activations stay resident on 288 GB parts."""
+        """Nothing to wrap: the training strategy plans the replay itself (TrainStep(recompute=True), chosen when the
+        saved activations would not fit in HBM — training/strategy.py)."""
 
     def get_fsdp_wrapping_policy(self) -> Sequence[str]:
         return ("llm.layerNN", "llm.lm_head")

@@ -225,10 +225,14 @@ class TrainStep:
     def __init__(self, weights: VLAWeights, stage: str, batch: int, prompt_len: int, *, max_grad_norm: float = 1.0,
                  weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8, store: Optional[ParamStore] = None,
                  world: int = 1, rank: int = 0, group=None, reduce_dtype: torch.dtype = torch.float32, lora=None,
-                 force_comm: bool = False):
-        """`lora`: a training.lora.LoraAdapters → stage "lora": the base model is frozen and only the adapters train."""
+                 force_comm: bool = False, recompute: bool = False):
+        """`lora`: a training.lora.LoraAdapters → stage "lora": the base model is frozen and only the adapters train.
+        `recompute`: keep only each decoder layer's input and replay its forward inside the backward pass."""
         if (lora is not None) != (stage == "lora"):
             raise ValueError("stage 'lora' and the `lora` adapters go together")
+        if recompute and lora is not None:
+            raise ValueError("activation recomputation is planned for the full-parameter stages only")
+        self.recompute = recompute
         self.lora = lora
         self.train_vision = STAGES[stage][0] or lora is not None      # towers need their training-form forward
         self.w, self.dims, self.stage = weights, weights.dims, stage
@@ -280,15 +284,22 @@ class TrainStep:
         self.z1, self.z2, self.p3 = z(B * 256, Pv), z(B * 256, D), z(B * 256, D)
         self.p1, self.p2 = za(B * 256, Pv, R_(weights.fc2_w)), za(B * 256, D, R_(weights.fc3_w))
         self.x = [z(Tn, D) for _ in range(NL + 1)]            # residual stream entering layer l (x[NL] = final)
-        self.xm = [z(Tn, D) for _ in range(NL)]
-        self.h1 = [za(Tn, D, R_(L0.qkv_w)) for _ in range(NL)]
-        self.h2 = [za(Tn, D, R_(L0.gu_w)) for _ in range(NL)]
-        self.qkv = [za(Tn, 3 * D, R_(L0.qkv_w)) for _ in range(NL)]     # same leading dimension as dqkv (shared strides)
-        self.ao = [za(Tn, D, R_(L0.o_w)) for _ in range(NL)]
-        self.gu = [z(Tn, 2 * I) for _ in range(NL)]
-        self.act = [za(Tn, I, R_(L0.down_w)) for _ in range(NL)]
+        # per-layer saved activations; with `recompute` (the reference's activation checkpointing of the decoder layers,
+        # fsdp.py:171-183) every layer shares ONE set and only the layer inputs x[l] are kept
+        def per_layer(make):
+            if not recompute:
+                return [make() for _ in range(NL)]
+            one = make()
+            return [one] * NL
+        self.xm = per_layer(lambda: z(Tn, D))
+        self.h1 = per_layer(lambda: za(Tn, D, R_(L0.qkv_w)))
+        self.h2 = per_layer(lambda: za(Tn, D, R_(L0.gu_w)))
+        self.qkv = per_layer(lambda: za(Tn, 3 * D, R_(L0.qkv_w)))     # same leading dimension as dqkv (shared strides)
+        self.ao = per_layer(lambda: za(Tn, D, R_(L0.o_w)))
+        self.gu = per_layer(lambda: z(Tn, 2 * I))
+        self.act = per_layer(lambda: za(Tn, I, R_(L0.down_w)))
         pad = (S + 31) // 32 * 32
-        self.lse = [z(B * d.llm_heads * pad, dtype=torch.float32) for _ in range(NL)]
+        self.lse = per_layer(lambda: z(B * d.llm_heads * pad, dtype=torch.float32))
         self.delta = z(B * d.llm_heads * pad, dtype=torch.float32)
         self.hn = z(Tn, D)
         self.logits = z(Tn, V, dtype=torch.float32)
@@ -452,21 +463,32 @@ class TrainStep:
         plan += lin(self.p2, w.fc3_w, self.p3, EPI_BIAS, bias=w.fc3_b)
         plan += [T.map_rows(self.p3, self.x[0], rows=B * 256, group=256, stride=S, offset=1, scatter=True, run=False),
                  ops.embed_splice(self.input_ids, w.embed, self.x[0].view(B, S, D), d.n_patches, run=False)]
-        lq, lo = self.qkv[0].stride(0), self.ao[0].stride(0)
-        st, so = (S * lq, hd, lq), (S * lo, hd, lo)
-        for l, lw in enumerate(w.layers):
-            x, xm, qkv = self.x[l], self.xm[l], self.qkv[l]
-            plan += [ops.rmsnorm(x, lw.ln1, self.h1[l], d.rms_eps, run=False)] + lin(self.h1[l], lw.qkv_w, qkv, EPI_NONE)
-            plan += [T.rope(qkv, self.cos, self.sin, B=B, S=S, H=H, head_dim=hd, run=False),
-                     T.attention_lse(qkv, qkv[:, D:], qkv[:, 2 * D:], self.ao[l], self.lse[l], B=B, H=H, Sq=S, Skv=S,
-                                     head_dim=hd, q_strides=st, k_strides=st, v_strides=st, o_strides=so,
-                                     causal=True, key_mask=self.key_mask, run=False)]
-            plan += lin(self.ao[l], lw.o_w, xm, EPI_RES, res=x)
-            plan += [ops.rmsnorm(xm, lw.ln2, self.h2[l], d.rms_eps, run=False)] + lin(self.h2[l], lw.gu_w, self.gu[l], EPI_NONE)
-            plan += [T.swiglu(self.gu[l], self.act[l], run=False)] + lin(self.act[l], lw.down_w, self.x[l + 1], EPI_RES, res=xm)
+        for l in range(d.llm_layers):
+            plan += self._layer_forward(l)
         plan += [ops.rmsnorm(self.x[-1], w.norm, self.hn, d.rms_eps, run=False),
                  g(self.hn, w.lm_head, self.logits, EPI_F32_BF16R),
                  ops.cross_entropy(self.logits, self.targets, self.row_loss, self.mean_cnt, IGNORE_INDEX, run=False)]
+        return plan
+
+    def _layer_forward(self, l: int, with_down: bool = True) -> List[Op]:
+        """Forward ops of decoder layer l from its saved input x[l] (modeling_llama.py LlamaDecoderLayer). The backward
+        plan replays them (without the down projection, whose output is x[l+1]) when activations are recomputed."""
+        d, w, B, S = self.dims, self.w, self.B, self.S
+        D, H, hd = d.llm_dim, d.llm_heads, d.head_dim
+        lin, lw = self._lin, w.layers[l]
+        lq, lo = self.qkv[0].stride(0), self.ao[0].stride(0)
+        st, so = (S * lq, hd, lq), (S * lo, hd, lo)
+        x, xm, qkv = self.x[l], self.xm[l], self.qkv[l]
+        plan = [ops.rmsnorm(x, lw.ln1, self.h1[l], d.rms_eps, run=False)] + lin(self.h1[l], lw.qkv_w, qkv, EPI_NONE)
+        plan += [T.rope(qkv, self.cos, self.sin, B=B, S=S, H=H, head_dim=hd, run=False),
+                 T.attention_lse(qkv, qkv[:, D:], qkv[:, 2 * D:], self.ao[l], self.lse[l], B=B, H=H, Sq=S, Skv=S,
+                                 head_dim=hd, q_strides=st, k_strides=st, v_strides=st, o_strides=so,
+                                 causal=True, key_mask=self.key_mask, run=False)]
+        plan += lin(self.ao[l], lw.o_w, xm, EPI_RES, res=x)
+        plan += [ops.rmsnorm(xm, lw.ln2, self.h2[l], d.rms_eps, run=False)] + lin(self.h2[l], lw.gu_w, self.gu[l], EPI_NONE)
+        plan += [T.swiglu(self.gu[l], self.act[l], run=False)]
+        if with_down:
+            plan += lin(self.act[l], lw.down_w, self.x[l + 1], EPI_RES, res=xm)
         return plan
 
     def _plan_backward(self) -> List[Op]:
@@ -487,6 +509,8 @@ class TrainStep:
         stop_layer = self._lowest_needed_layer()
         for l in range(d.llm_layers - 1, stop_layer - 1, -1):
             lw, b = w.layers[l], f"{lm}.layers.{l}"
+            if self.recompute and l != d.llm_layers - 1:       # the top layer's activations are still in the shared set
+                plan += self._layer_forward(l, with_down=False)
             plan += lb(dx, self.act[l], lw.down_w, self.dact)
             plan.append(T.swiglu_backward(self.gu[l], self.dact, self.dgu, run=False))
             plan += lb(self.dgu, self.h2[l], lw.gu_w, self.dh)

@@ -143,7 +143,8 @@ class ShardedOptimizerStrategy:
                  lr_scheduler_type: str, warmup_ratio: float, enable_gradient_checkpointing: bool = True,
                  enable_mixed_precision_training: bool = True, reduce_in_full_precision: bool = False,
                  mixed_precision_dtype: torch.dtype = torch.bfloat16, worker_init_fn: Optional[Callable[[int], None]] = None,
-                 sharding_strategy: str = "shard-grad-op", max_text_len: int = 48, **_: Any) -> None:
+                 sharding_strategy: str = "shard-grad-op", max_text_len: int = 48,
+                 recompute_activations: Optional[bool] = None, **_: Any) -> None:
         if stage not in STAGES:
             raise ValueError(f"Stage `{stage}` is not supported")
         if sharding_strategy not in ("shard-grad-op", "full-shard"):
@@ -164,6 +165,11 @@ class ShardedOptimizerStrategy:
                                                       ("llm_backbone", llm != "none")) if on]
         self.all_module_keys = list(self.ALL_MODULE_KEYS)
         self.max_text_len = max_text_len
+        # the reference checkpoints every decoder layer when `enable_gradient_checkpointing` (fsdp.py:171-183) because
+        # 80 GB parts cannot keep the activations; here they stay resident unless they would not fit (None = decide from
+        # free HBM when the step is planned), and True / False force either form
+        self.enable_gradient_checkpointing = enable_gradient_checkpointing
+        self.recompute_activations = recompute_activations
         self.store: Optional[ParamStore] = None
         self.step_engine: Optional[TrainStep] = None
         self.num_training_steps = self.num_warmup_steps = 0
@@ -188,9 +194,20 @@ class ShardedOptimizerStrategy:
             torch.cuda.empty_cache()
             self.step_engine = TrainStep(
                 self.vlm.weights, self.stage, self.per_device_batch_size, L, max_grad_norm=self.max_grad_norm,
-                weight_decay=self.weight_decay, store=self.store,
+                weight_decay=self.weight_decay, store=self.store, recompute=self._want_recompute(L),
                 reduce_dtype=torch.float32 if self.reduce_in_full_precision else torch.bfloat16)
         return self.step_engine
+
+    def _want_recompute(self, L: int) -> bool:
+        if self.recompute_activations is not None:
+            return bool(self.recompute_activations) and self.enable_gradient_checkpointing
+        if not self.enable_gradient_checkpointing:
+            return False
+        d = self.vlm.weights.dims
+        tokens = self.per_device_batch_size * (L + d.n_patches)
+        saved = tokens * d.llm_layers * (8 * d.llm_dim + 3 * d.llm_inter) * 2        # bytes of per-layer activations
+        free, _ = torch.cuda.mem_get_info(self.vlm.weights.embed.device)
+        return saved > 0.8 * free
 
     def clip_grad_norm(self) -> torch.Tensor:
         return self.step_engine.clip_grad_norm()

@@ -140,6 +140,39 @@ def test_graph_replay_equals_eager_over_steps(dev, stage):
     assert torch.equal(out[False][1], out[True][1])
 
 
+@pytest.mark.parametrize("stage", ["vla-train", "vla-full-train"])
+def test_recompute_equals_saved_activations(dev, stage):
+    """Activation recomputation (the reference's checkpointing of the decoder layers, fsdp.py:171-183) replays each
+    layer's forward with the same kernels on the same saved input, so losses, norms and masters stay bit-identical while
+    the per-layer activation sets collapse into one."""
+    from bridgelang_amd.training.step import TrainStep
+    from bridgelang_amd.weights import allocate, tiny_dims
+    dims = tiny_dims()
+    out = {}
+    for rc in (False, True):
+        w = allocate(dims, dev).fill_synthetic(seed=5)
+        ts = TrainStep(w, stage, 2, 18, max_grad_norm=1.0, weight_decay=0.1, recompute=rc)
+        log = []
+        for step in range(3):
+            ids, mask, labels, pv = make_batch(dims, 2, 18, seed=30 + step)
+            ts.set_batch(ids, mask, pv, labels)
+            loss, norm = ts.step(1e-3, graph=(step == 2))
+            log.append((loss.item(), norm.item()))
+        out[rc] = (log, ts.store.full_master().cpu(), len({t.data_ptr() for t in ts.gu}), len({t.data_ptr() for t in ts.x}))
+    assert out[False][0] == out[True][0]
+    assert torch.equal(out[False][1], out[True][1])
+    assert out[False][2] == dims.llm_layers and out[True][2] == 1 and out[True][3] == dims.llm_layers + 1
+
+
+def test_recompute_rejected_with_adapters(dev):
+    from bridgelang_amd.training.lora import LoraAdapters
+    from bridgelang_amd.training.step import TrainStep
+    from bridgelang_amd.weights import allocate, tiny_dims
+    w = allocate(tiny_dims(), dev).fill_synthetic(seed=5)
+    with pytest.raises(ValueError):
+        TrainStep(w, "lora", 2, 18, lora=LoraAdapters(w, r=8), recompute=True)
+
+
 def test_edge_cases_max_length_and_unsupervised_sample(dev):
     """(i) the longest plannable sequence (S = 320 = 256 patches + 64 text tokens) still matches autograd; (ii) a sample
     with no supervised token contributes nothing (HF ignore_index semantics); (iii) over-long plans are rejected."""
