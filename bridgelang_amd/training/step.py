@@ -509,7 +509,7 @@ class TrainStep:
         stop_layer = self._lowest_needed_layer()
         for l in range(d.llm_layers - 1, stop_layer - 1, -1):
             lw, b = w.layers[l], f"{lm}.layers.{l}"
-            if self.recompute and l != d.llm_layers - 1:       # the top layer's activations are still in the shared set
+            if self.recompute:         # incl. the top layer: the plan stays idempotent (graph capture runs it twice)
                 plan += self._layer_forward(l, with_down=False)
             plan += lb(dx, self.act[l], lw.down_w, self.dact)
             plan.append(T.swiglu_backward(self.gu[l], self.dact, self.dgu, run=False))
