@@ -68,6 +68,7 @@ SIGNATURES = {
     "bl_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "bl_gemm_skinny_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "bl_gemm_skinny_rows_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "bl_gemm_tn_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "bl_rmsnorm_skinny_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "bl_layernorm_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "bl_rmsnorm_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),

@@ -55,6 +55,7 @@ __device__ __forceinline__ void tile_coords(const GemmArgs& p, int& tm, int& tn)
 }
 
 #define BL_GLDS(RS, LDSP, VOFF, SOFF) __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, LDS_PTR(LDSP), 16, VOFF, SOFF, 0, 0)
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;   // result of ds_read_b64_tr_b16
 
 // ======================================================================================================================
 // 128 × 128 tile
@@ -1135,7 +1136,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 // (Tried and rejected: prefetching the next phase's fragments inside the group's own MMA segment — hipcc serialises the
 // reads ahead of the MFMAs, the MMA segment grows, 1430 → 1286 TFLOP/s.)
 // ======================================================================================================================
-template <int EPI>
+template <int EPI, bool TN = false>
 __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 256, BN = 256;
@@ -1143,7 +1144,7 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   int tm, tn;
-  const int nk_all = p.K / BK;
+  const int nk_all = TN ? (p.K + BK - 1) / BK : p.K / BK;
   int kt_begin = 0, nk = nk_all;
   if (p.splitk > 1) {
     lin_to_tile(p, p.tail_base + blockIdx.x / p.splitk, tm, tn);
@@ -1160,30 +1161,58 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
   const int l15 = lane & 15, lg = lane >> 4;
   const int kt32 = p.K >> 5;
 
-  const unsigned a_bytes = (unsigned)min((long)p.M * p.lda * 2, 0xffffffffL);
-  const unsigned w_bytes = (unsigned)min((long)p.N * p.K * 2, 0xffffffffL);
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0, 0x00020000);
+  // TN (C = Aᵀ·B, the weight gradient dW = dyᵀ·x read UNtransposed): A is [K tokens, M] and W is [K tokens, N], both
+  // row-major; a K-tile is 64 token rows of each. The descriptors end with the last token row's last column (the exact
+  // extent of a column-slice view), so K-tiles past the end and the ragged last one read zeros.
+  const unsigned a_bytes = (unsigned)min(TN ? ((long)(p.K - 1) * p.lda + p.M) * 2 : (long)p.M * p.lda * 2, 0xffffffffL);
+  const unsigned w_bytes = (unsigned)min(TN ? ((long)(p.K - 1) * p.ldw + p.N) * 2 : (long)p.N * p.K * 2, 0xffffffffL);
+  const int kstepX = TN ? (int)(64 * p.lda * 2) : 128, kstepY = TN ? (int)(64 * p.ldw * 2) : 2048;
 
   const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
   unsigned voffX[2][2], voffY[2][2];
   int ldsX[2][2], ldsY[2];
+  if constexpr (!TN) {
 #pragma unroll
-  for (int mh = 0; mh < 2; ++mh)
+    for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int pi = 2 * wave + j, row0 = (pi >> 3) * 128 + mh * 64 + (pi & 7) * 8;
-      voffX[mh][j] = (unsigned)(((long)(m0 + row0 + prow) * p.lda) * 2 + pchunk * 16);
-      ldsX[mh][j] = row0 * ROW_BYTES;
+      for (int j = 0; j < 2; ++j) {
+        const int pi = 2 * wave + j, row0 = (pi >> 3) * 128 + mh * 64 + (pi & 7) * 8;
+        voffX[mh][j] = (unsigned)(((long)(m0 + row0 + prow) * p.lda) * 2 + pchunk * 16);
+        ldsX[mh][j] = row0 * ROW_BYTES;
+      }
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      const int nt = (wave >> 1) * 4 + 2 * nh + (wave & 1);
+      voffY[nh][0] = (unsigned)((long)(n0 / 16 + nt) * kt32 * 1024 + lane * 16);
+      voffY[nh][1] = voffY[nh][0] + 1024;
+      ldsY[nh] = W_OFF + nt * 2048;
     }
+  } else {
+    // LDS keeps the NT kernel's regions but token-major inside them: X block (wm', mh) = [64 tokens][64 columns = 128 B],
+    // Y half nh = [64 tokens][128 columns = 256 B]. The fragments come from transposing reads (ds_read_b64_tr_b16:
+    // a 32-lane half touches 8 token rows × 32 B), so 32-byte chunk PAIRS are swizzled against the token index:
+    // X pair' = pair ^ ((t >> 1) & 3), Y pair' = pair ^ (t & 7) — the 8 rows then cover all 64 banks once.
 #pragma unroll
-  for (int nh = 0; nh < 2; ++nh) {
-    const int nt = (wave >> 1) * 4 + 2 * nh + (wave & 1);
-    voffY[nh][0] = (unsigned)((long)(n0 / 16 + nt) * kt32 * 1024 + lane * 16);
-    voffY[nh][1] = voffY[nh][0] + 1024;
-    ldsY[nh] = W_OFF + nt * 2048;
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int pi = 2 * wave + j, t = (pi & 7) * 8 + prow, pos = lane & 7;
+        const int c = ((((pos >> 1) ^ ((t >> 1) & 3)) << 1) | (pos & 1));
+        voffX[mh][j] = (unsigned)((long)t * p.lda * 2 + (long)(m0 + (pi >> 3) * 128 + mh * 64) * 2 + c * 16);
+        ldsX[mh][j] = ((pi >> 3) * 128 + mh * 64 + (pi & 7) * 8) * ROW_BYTES;
+      }
+    // Y half nh = columns nh*128 .. +127 of the tile: [64 tokens][256 B], whole 128-byte lines per piece (4 token rows × 256 B;
+    // a 64-byte-segment layout made every line travel twice: −30 %). Wave wn computes columns nh*128 + wn*32 + j*16 + (0..15).
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int t = (2 * wave + j) * 4 + (lane >> 4), pos = lane & 15;
+        const int c = ((((pos >> 1) ^ (t & 7)) << 1) | (pos & 1));
+        voffY[nh][j] = (unsigned)((long)t * p.ldw * 2 + (long)(n0 + nh * 128) * 2 + c * 16);
+      }
+      ldsY[nh] = W_OFF + nh * 16384 + wave * 2048;
+    }
   }
 // past the end of K the descriptor's size is 0 (the load then writes zeros): only that one dword of it varies
 #define BL_RS(PTR, BYTES) __builtin_amdgcn_make_buffer_rsrc((void*)(PTR), 0, (BYTES), 0x00020000)
@@ -1192,38 +1221,87 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
     const int t__ = (TILE);                                                                 \
     const __amdgpu_buffer_rsrc_t rs__ = BL_RS(p.A, t__ < nk ? a_bytes : 0u);                \
     char* b__ = smem + (t__ & 1) * STAGE;                                                   \
-    BL_GLDS(rs__, b__ + ldsX[MH][0], voffX[MH][0], t__ * 128);                              \
-    BL_GLDS(rs__, b__ + ldsX[MH][1], voffX[MH][1], t__ * 128);                              \
+    BL_GLDS(rs__, b__ + ldsX[MH][0], voffX[MH][0], t__ * kstepX);                              \
+    BL_GLDS(rs__, b__ + ldsX[MH][1], voffX[MH][1], t__ * kstepX);                              \
   } while (0)
 #define ISSUE_Y(NH, TILE)                                                                   \
   do {                                                                                      \
     const int t__ = (TILE);                                                                 \
     const __amdgpu_buffer_rsrc_t rs__ = BL_RS(p.W, t__ < nk ? w_bytes : 0u);                \
     char* b__ = smem + (t__ & 1) * STAGE;                                                   \
-    BL_GLDS(rs__, b__ + ldsY[NH], voffY[NH][0], t__ * 2048);                                \
-    BL_GLDS(rs__, b__ + ldsY[NH] + 1024, voffY[NH][1], t__ * 2048);                         \
+    BL_GLDS(rs__, b__ + ldsY[NH], voffY[NH][0], t__ * kstepY);                                \
+    BL_GLDS(rs__, b__ + ldsY[NH] + 1024, voffY[NH][1], t__ * kstepY);                         \
   } while (0)
   const int cb0 = (lg ^ (lane & 7)) << 4;
   const int offX = (wm * 128 + l15) * ROW_BYTES;
   const int offY = W_OFF + wn * 8192 + lane * 16;
+  // TN: lane 4q+u of a 16-lane group addresses token row 4·lg + q, 8-byte unit u of the 16-column block and receives
+  // column l15 of the four rows; the second read is 16 tokens further → slots 0-3 / 4-7 of the MFMA operand hold tokens
+  // {4lg..4lg+3} and {16+4lg..}, the same for both operands.
+  const int trX = (wm * 128) * ROW_BYTES + (4 * lg + (l15 >> 2)) * 128 + (l15 & 3) * 8, swX = ((lg & 1) << 1) | (l15 >> 3);
+  const int trY = W_OFF + (4 * lg + (l15 >> 2)) * 256 + (l15 & 3) * 8, swY = ((lg & 1) << 2) | (l15 >> 2);
+  // The transposing reads are inline asm: through the builtin, hipcc orders every one of them behind ALL outstanding LDS-DMA
+  // (`s_waitcnt vmcnt(0)` before each read group — the intrinsic carries no memory operand to disambiguate), which
+  // serialises the staging pipeline (−30 %). The asm results land asynchronously, so they are only touched after the
+  // explicit lgkmcnt wait + barrier that precede every MMA, where BL_PIN marks them as produced.
+  const unsigned ldsbase = (unsigned)(size_t)LDS_PTR(smem);
+#define BL_TR(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define BL_PIN(R) asm volatile("" : "+v"(R))
 #define READ_X(DST, MH, SB)                                                                             \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
-    DST[i * 2] = *(const bf16x8_t*)((SB) + offX + (MH) * 8192 + i * 2048 + cb0);                        \
-    DST[i * 2 + 1] = *(const bf16x8_t*)((SB) + offX + (MH) * 8192 + i * 2048 + (cb0 ^ 64));            \
-  }
+  do {                                                                                                  \
+    if constexpr (!TN) {                                                                                \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+        DST[i * 2] = *(const bf16x8_t*)((SB) + offX + (MH) * 8192 + i * 2048 + cb0);                    \
+        DST[i * 2 + 1] = *(const bf16x8_t*)((SB) + offX + (MH) * 8192 + i * 2048 + (cb0 ^ 64));        \
+      }                                                                                                 \
+    } else {                                                                                            \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+        const unsigned a__ = ldsbase + (unsigned)((SB) - smem) + trX + ((i ^ swX) << 5);                \
+        BL_TR(DST##2[i * 4 + 0], a__, (MH) * 8192);                                                     \
+        BL_TR(DST##2[i * 4 + 1], a__, (MH) * 8192 + 2048);                                              \
+        BL_TR(DST##2[i * 4 + 2], a__, (MH) * 8192 + 4096);                                              \
+        BL_TR(DST##2[i * 4 + 3], a__, (MH) * 8192 + 4096 + 2048);                                       \
+      }                                                                                                 \
+    }                                                                                                   \
+  } while (0)
 #define READ_Y(DST, NH, SB)                                                                             \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
-    DST[j * 2] = *(const bf16x8_t*)((SB) + offY + (2 * (NH) + j) * 2048);                               \
-    DST[j * 2 + 1] = *(const bf16x8_t*)((SB) + offY + (2 * (NH) + j) * 2048 + 1024);                    \
-  }
+  do {                                                                                                  \
+    if constexpr (!TN) {                                                                                \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                   \
+        DST[j * 2] = *(const bf16x8_t*)((SB) + offY + (2 * (NH) + j) * 2048);                           \
+        DST[j * 2 + 1] = *(const bf16x8_t*)((SB) + offY + (2 * (NH) + j) * 2048 + 1024);                \
+      }                                                                                                 \
+    } else {                                                                                            \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                   \
+        const unsigned a__ = ldsbase + (unsigned)((SB) - smem) + trY + (((wn * 2 + j) ^ swY) << 5);     \
+        BL_TR(DST##2[j * 4 + 0], a__, (NH) * 16384);                                                    \
+        BL_TR(DST##2[j * 4 + 1], a__, (NH) * 16384 + 4096);                                             \
+        BL_TR(DST##2[j * 4 + 2], a__, (NH) * 16384 + 8192);                                             \
+        BL_TR(DST##2[j * 4 + 3], a__, (NH) * 16384 + 8192 + 4096);                                      \
+      }                                                                                                 \
+    }                                                                                                   \
+  } while (0)
+// TN fragments: DST2[f * 4 + ks * 2 + half] (8 bytes each); operand ks of fragment f = {[f*4 + 2ks], [f*4 + 2ks + 1]}
+#define BL_FRAG(R2, F, KS)                                                                              \
+  __builtin_bit_cast(bf16x8_t, ((u32x4_t){R2[(F) * 4 + 2 * (KS)][0], R2[(F) * 4 + 2 * (KS)][1],         \
+                                          R2[(F) * 4 + 2 * (KS) + 1][0], R2[(F) * 4 + 2 * (KS) + 1][1]}))
 #define MMA(XR, YR, MH, NH)                                                                             \
   do {                                                                                                  \
+    if constexpr (TN) {                                                                                 \
+      _Pragma("unroll") for (int q = 0; q < 16; ++q) BL_PIN(XR##2[q]);                                  \
+      _Pragma("unroll") for (int q = 0; q < 8; ++q) BL_PIN(YR##2[q]);                                   \
+    }                                                                                                   \
     __builtin_amdgcn_s_setprio(1);                                                                      \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
-          acc[2 * (NH) + j][4 * (MH) + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                    \
-              YR[j * 2 + ks], XR[i * 2 + ks], acc[2 * (NH) + j][4 * (MH) + i], 0, 0, 0);                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                 \
+          if constexpr (TN)                                                                             \
+            acc[2 * (NH) + j][4 * (MH) + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                  \
+                BL_FRAG(YR##2, j, ks), BL_FRAG(XR##2, i, ks), acc[2 * (NH) + j][4 * (MH) + i], 0, 0, 0); \
+          else                                                                                          \
+            acc[2 * (NH) + j][4 * (MH) + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                  \
+                YR[j * 2 + ks], XR[i * 2 + ks], acc[2 * (NH) + j][4 * (MH) + i], 0, 0, 0);              \
+        }                                                                                               \
     __builtin_amdgcn_s_setprio(0);                                                                      \
   } while (0)
 // (the timing-only variants of these four macros — no barrier / no wait / no issue / no reads — are generated into a
@@ -1258,7 +1336,9 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
     } else {                                                                                              \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
         _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                     \
-          epilogue_store4<EPI>(p, m0 + wm * 128 + j * 16 + l15, n0 + wn * 64 + i * 16 + lg * 4, acc[i][j]); \
+          epilogue_store4<EPI>(p, m0 + wm * 128 + j * 16 + l15,                                           \
+                               TN ? n0 + (i >> 1) * 128 + wn * 32 + (i & 1) * 16 + lg * 4                 \
+                                  : n0 + wn * 64 + i * 16 + lg * 4, acc[i][j]);                           \
     }                                                                                                     \
   } while (0)
 
@@ -1267,7 +1347,8 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  bf16x8_t X[8], Ya[4], Yb[4];
+  bf16x8_t X[8], Ya[4], Yb[4];            // NT fragments (unused and eliminated in the TN form)
+  u32x2_t X2[16], Ya2[8], Yb2[8];         // TN fragments, one 8-byte transposing read each
   char* const S0 = smem;
   char* const S1 = smem + STAGE;
   const int t0 = kt_begin;
@@ -1318,6 +1399,9 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
 #undef ISSUE_Y
 #undef READ_X
 #undef READ_Y
+#undef BL_TR
+#undef BL_PIN
+#undef BL_FRAG
 #undef MMA
 #undef BAR
 #undef WAIT_VM8
@@ -1334,7 +1418,7 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
 // Sum the split-K slabs of the leftover tiles and apply the fused epilogue. Same thread → (m, n) map as the 256x256
 // kernels; grid = leftover tiles × 32: one block per accumulator vector (i, j) of a tile, so the slab reads are spread
 // over ≥ 1024 workgroups instead of 128.
-template <int EPI>
+template <int EPI, bool TN = false>
 __global__ __launch_bounds__(512) void gemm_splitk_reduce_kernel(GemmArgs p) {
   int tm, tn;
   const int tile_local = blockIdx.x >> 5, idx = blockIdx.x & 31, i = idx >> 3, j = idx & 7;
@@ -1344,7 +1428,8 @@ __global__ __launch_bounds__(512) void gemm_splitk_reduce_kernel(GemmArgs p) {
   f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < p.splitk; ++s)
     sum += *(const f32x4_t*)(p.slab + (((long)(tile_local * p.splitk + s) * 32 + idx) * 512 + tid) * 4);
-  epilogue_store4<EPI>(p, tm * 256 + wm * 128 + j * 16 + l15, tn * 256 + wn * 64 + i * 16 + lg * 4, sum);
+  epilogue_store4<EPI>(p, tm * 256 + wm * 128 + j * 16 + l15,
+                       TN ? tn * 256 + (i >> 1) * 128 + wn * 32 + (i & 1) * 16 + lg * 4 : tn * 256 + wn * 64 + i * 16 + lg * 4, sum);
 }
 
 template <int MB, int NB>
@@ -1593,6 +1678,44 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   return BL_OK;
 }
 
+// bl_gemm_tn_bf16: C[M, N] (fp32) = Aᵀ·B over K token rows, A = [K, M] and B = [K, N] row-major — the weight gradient
+// dW = dyᵀ·x straight from the row-major gradient and activation buffers (no transposed copies). Whole rounds of 256 × 256
+// tiles on the staggered kernel's TN form; a partial last round is split along K when the caller gave a workspace.
+int launch_gemm_tn(const GemmArgs& a, hipStream_t s) {
+  constexpr int CUS = 256, LDS256 = 2 * 65536;
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<BL_EPI_F32, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS256) != hipSuccess)
+      return BL_E_LAUNCH;
+    done = true;
+  }
+  GemmArgs p = a;
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  const int tiles = p.tiles_m * p.tiles_n, nk = (p.K + BK - 1) / BK;
+  // fewer tiles than half the CUs (ViT blocks: 16 … 85 tiles): every tile is K-split so the launch fills the chip
+  int tail = tiles > CUS ? tiles % CUS : (2 * tiles <= CUS ? tiles : 0);
+  int S = tail ? CUS / tail : 1;
+  if (tiles <= CUS && S > 8) S = 8;
+  if (S > 16) S = 16;
+  while (S > 1 && nk / S < 4) --S;
+  static const bool no_split = getenv("BL_GEMM_NO_SPLITK") != nullptr;
+  const bool can_split = tail && S >= 2 && (nk >= 128 || tiles <= CUS) && p.slab &&
+                         p.slab_bytes >= (long)tail * S * 256 * 256 * 4 && !no_split;
+  if (can_split) {
+    if (tiles > tail) hipLaunchKernelGGL((gemm256s_kernel<BL_EPI_F32, true>), dim3(tiles - tail), dim3(512), LDS256, s, p);
+    p.tail_base = tiles - tail;
+    p.splitk = S;
+    hipLaunchKernelGGL((gemm256s_kernel<BL_EPI_F32, true>), dim3(tail * S), dim3(512), LDS256, s, p);
+    hipLaunchKernelGGL((gemm_splitk_reduce_kernel<BL_EPI_F32, true>), dim3(tail * 32), dim3(512), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((gemm256s_kernel<BL_EPI_F32, true>), dim3(tiles), dim3(512), LDS256, s, p);
+  }
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
 }  // namespace bl_gemm_bf16_impl
 using namespace bl_gemm_bf16_impl;
 
@@ -1630,4 +1753,21 @@ extern "C" int bl_gemm_skinny_rows_bf16(const bl_gemm_desc* d, void* stream) {
     case BL_EPI_F32_BF16R: return launch_rows_sk<BL_EPI_F32_BF16R>(a, s);
     default: return BL_E_ARG;
   }
+}
+
+extern "C" int bl_gemm_tn_bf16(const bl_gemm_desc* d, void* stream) {
+  if (!d || !d->A || !d->W || !d->C) return BL_E_ARG;
+  if (d->epilogue != BL_EPI_F32 || d->out_group || d->a_norm_weight) return BL_E_ARG;
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->M % 8) || (d->N % 8)) return BL_E_SHAPE;
+  if ((d->lda % 8) || (d->ldw % 8) || (d->ldc % 4) || d->lda < d->M || d->ldw < d->N || d->ldc < d->N) return BL_E_ALIGN;
+  if (!bl_aligned16(d->A) || !bl_aligned16(d->W) || (((uintptr_t)d->C) & 15)) return BL_E_ALIGN;
+  // byte offsets inside the kernel are 32-bit (buffer addressing)
+  if ((long)d->K * d->lda * 2 >= (1L << 31) || (long)d->K * d->ldw * 2 >= (1L << 31)) return BL_E_SHAPE;
+  GemmArgs a = {};
+  a.A = d->A; a.W = d->W; a.C = d->C;
+  a.lda = d->lda; a.ldw = d->ldw; a.ldc = d->ldc;
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.tail_base = -1;
+  a.slab = (float*)d->workspace; a.slab_bytes = d->workspace_bytes; a.splitk = 1;
+  return launch_gemm_tn(a, (hipStream_t)stream);
 }

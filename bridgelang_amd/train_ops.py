@@ -206,6 +206,26 @@ def transpose_pack(a: torch.Tensor, out_packed: torch.Tensor, rows_pad: int, run
                                           rows_pad), (a, out_packed), run, nbytes=2.0 * cols * (rows + rows_pad))
 
 
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor, workspace: Optional[torch.Tensor] = None, run: bool = True) -> Op:
+    """out[N, K] (fp32) = dyᵀ·x over the token rows: dy [T, N], x [T, K] row-major bf16 (column-slice views allowed) — the
+    weight gradient of y = x·Wᵀ read straight from the buffers the backward pass already holds (bl_gemm_tn_bf16)."""
+    from .ops import EPI_F32, GemmDesc
+    Tn, N = dy.shape
+    K = x.shape[1]
+    if x.shape[0] != Tn or tuple(out.shape) != (N, K):
+        raise ValueError(f"gemm_tn: dy{tuple(dy.shape)} x{tuple(x.shape)} out{tuple(out.shape)}")
+    d = GemmDesc()
+    d.A, d.lda = _bf16(dy, "dy").data_ptr(), _rows(dy, "dy")
+    d.W, d.ldw = _bf16(x, "x").data_ptr(), _rows(x, "x")
+    d.C, d.ldc = _f32(out, "out").data_ptr(), _rows(out, "out")
+    d.M, d.N, d.K, d.epilogue = N, K, Tn, EPI_F32
+    keep = [d, dy, x, out]
+    if workspace is not None:
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+        keep.append(workspace)
+    return _op("bl_gemm_tn_bf16", (C.byref(d),), tuple(keep), run, flops=2.0 * Tn * N * K, nbytes=2.0 * Tn * (N + K) + 4.0 * N * K)
+
+
 def gemm_tn_small(P: torch.Tensor, Q: torch.Tensor, C: torch.Tensor, transpose_out: bool, ws: Optional[torch.Tensor] = None,
                   alpha: float = 1.0, run: bool = True) -> Op:
     """C = alpha · Pᵀ·Q over the rows: P [T, R] (R in 64/128/192), Q [T, N]; C fp32 [R, N] or, transposed, [N, R]."""

@@ -20,6 +20,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from .. import ops, train_ops as T
@@ -29,6 +31,7 @@ from ..weights import PackedGroup, VLAWeights, _block_view, _unpack
 from .sharding import ShardComm, ShardLayout, bucket_key, comm_order
 
 IGNORE_INDEX = -100
+WGRAD_NT = os.environ.get("BL_WGRAD_NT", "") not in ("", "0")     # A/B aid: weight gradients through transposed copies
 
 # stage → (vision trainable, projector trainable, llm: "all" | "last" | "none")   — prismatic.py:129-241
 STAGES: Dict[str, Tuple[bool, bool, str]] = {
@@ -361,10 +364,13 @@ class TrainStep:
         return self._g(dy, self.wT(packed), out, epilogue, **kw)
 
     def _wgrad_into(self, dy: torch.Tensor, x: torch.Tensor, gview: torch.Tensor) -> List[Op]:
-        """gview[N, K] (fp32) = dyᵀ[N, T] · x[T, K] as the NT GEMM over token-padded transposes."""
+        """gview[N, K] (fp32) = dyᵀ[N, T] · x[T, K]: the TN GEMM reads dy and x where they lie (transposing LDS reads);
+        BL_WGRAD_NT=1 keeps the round-1 form — the NT GEMM over token-padded transposed copies — as the A/B reference."""
         Tn, N = dy.shape
         K = x.shape[1]
         assert tuple(gview.shape) == (N, K), (dy.shape, x.shape, gview.shape)
+        if not WGRAD_NT and N % 8 == 0 and K % 8 == 0:
+            return [T.gemm_tn(dy, x, gview, workspace=self.ws, run=False)]
         Tp = (Tn + 63) // 64 * 64
         assert max(N, K) * Tp <= self.tA.numel()
         tA = self.tA[:N * Tp].view(N, Tp)

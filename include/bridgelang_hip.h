@@ -110,6 +110,12 @@ int bl_gemm_skinny_bf16(const bl_gemm_desc* d, void* stream);
  * K % 256 == 0; epilogues as bl_gemm_skinny_bf16; no out_map, no fused a_norm (see bl_rmsnorm_skinny_bf16). */
 int bl_gemm_skinny_rows_bf16(const bl_gemm_desc* d, void* stream);
 
+/* Weight gradient of an nn.Linear straight from row-major buffers: C[M, N] (fp32, BL_EPI_F32 only) = A^T * W with
+ * A = dy [K token rows, M] (lda) and W = x [K token rows, N] (ldw), both row-major bf16 — what autograd computes for
+ * `weight.grad` in loss.backward() (base_strategy.py:301; torch.nn.functional.linear backward). K is arbitrary (token
+ * rows past the end read as zeros); M, N multiples of 8. workspace (optional): fp32 scratch for a K-split last round. */
+int bl_gemm_tn_bf16(const bl_gemm_desc* d, void* stream);
+
 /* HF LlamaRMSNorm (transformers modeling_llama.py LlamaRMSNorm.forward; called per decoder layer from the cached-decode
  * branch, modeling_prismatic.py:325-341) in exactly the arithmetic of bl_gemm_skinny_bf16's fused a_norm (same
  * sum-of-squares order, same two roundings): y = bf16(w * bf16(x * rsqrt(mean(x^2) + eps))). dim in {512, 1024, 1536,

@@ -556,3 +556,29 @@ def test_gemm_mid_rows(dev, M, N, K, epi):
     assert torch.equal(out[:M], big[:M]), "a row's result must not depend on the number of rows in the call"
     ops.gemm(A[:M], W, out_ws[:M], code, workspace=torch.empty(64 << 20, dtype=torch.uint8, device=dev), **kws)
     close_bf16(out_ws[:M], ref, f"mid {epi} (K-sliced)")
+
+
+@pytest.mark.parametrize("Tn,N,K,pad", [(4736, 4096, 4096, 0), (300, 1152, 2176, 0), (261 * 4, 1024, 4096, 0),
+                                        (9472, 5632, 4096, 0), (1000, 512, 768, 64), (64, 256, 256, 0), (37, 264, 520, 8),
+                                        (4176, 3072, 1024, 0), (4176, 1152, 4304, 0)])
+def test_gemm_tn_matches_fp32_matmul(dev, Tn, N, K, pad):
+    """bl_gemm_tn_bf16: out[N, K] = dyᵀ·x read untransposed (weight gradient of nn.Linear; torch autograd's
+    `grad_output.t().mm(input)`). Ragged token counts, partial 256-tiles, column-slice views (ld > cols) and the K-split
+    last round (5632 x 4096: 352 tiles) against the fp32 product of the same bf16 values."""
+    from bridgelang_amd import train_ops as T
+    g = torch.Generator(device="cpu").manual_seed(Tn + N)
+    dyw = (torch.randn(Tn, N + pad, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    xw = torch.randn(Tn, K + pad, generator=g).to(torch.bfloat16).to(dev)
+    dy, x = dyw[:, pad:], xw[:, :K]
+    out = torch.full((N, K), float("nan"), dtype=torch.float32, device=dev)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    T.gemm_tn(dy, x, out, workspace=ws)
+    want = dy.float().t() @ x.float()
+    err = (out - want).abs().max().item()
+    scale = want.abs().max().item()
+    print(f"T={Tn} N={N} K={K}: max err {err:.3e} of {scale:.3e}")
+    assert torch.isfinite(out).all()
+    assert err <= 2e-5 * scale + 1e-4
+    out2 = torch.zeros_like(out)
+    T.gemm_tn(dy, x, out2)                      # no workspace: same tiles in one launch
+    assert (out2 - want).abs().max().item() <= 2e-5 * scale + 1e-4
