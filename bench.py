@@ -303,7 +303,7 @@ def train_main(args, rank: int, world: int, dev, distributed: bool) -> None:
         achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
         model_flops = sum(op.flops for op in plan)
         ms = elapsed / args.steps * 1e3
-        cfg_no = 3 if args.stage == "lora" else 2
+        cfg_no = 4 if args.model == "prism-13b" else 3 if args.stage == "lora" else 2
         line = {
             "metric": f"samples/sec {dims.name} {args.stage} bf16", "value": round(world * B * args.steps / elapsed, 3), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,

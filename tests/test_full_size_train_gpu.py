@@ -21,13 +21,16 @@ def _free_gpu_memory():
     torch.cuda.empty_cache()
 
 
-def test_lora_directional_derivative_full_size(dev):
+@pytest.mark.parametrize("model,B", [("7b", 16), ("13b", 8)])
+def test_lora_directional_derivative_full_size(dev, model, B):
+    """`13b`: the BASELINE configs[4] composition (Llama-2-13B widths: hidden 5120, 40 heads, inter 13824, 40 layers) —
+    the same property through the same training plan, which is what runs cfg 5's LoRA / per-rank step."""
     from bridgelang_amd import ops
     from bridgelang_amd.training.lora import LoraAdapters
     from bridgelang_amd.training.step import TrainStep
-    from bridgelang_amd.weights import allocate, openvla_7b_dims
-    B, L = 16, 32
-    w = allocate(openvla_7b_dims(), dev).fill_synthetic(seed=0)
+    from bridgelang_amd.weights import allocate, openvla_7b_dims, prism_13b_dims
+    L = 32
+    w = allocate(openvla_7b_dims() if model == "7b" else prism_13b_dims(), dev).fill_synthetic(seed=0)
     lora = LoraAdapters(w, r=32)
     ts = TrainStep(w, "lora", B, L, lora=lora, max_grad_norm=float("inf"), weight_decay=0.01)
     g = torch.Generator().manual_seed(0)
