@@ -62,6 +62,8 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--reduce", default="fp32", choices=["fp32", "bf16"], help="--mode train: gradient wire format")
     ap.add_argument("--recompute", action="store_true",
                     help="--mode train: keep only the decoder layers' inputs and replay each layer in backward (fsdp.py:171-183)")
+    ap.add_argument("--shard-params", action="store_true",
+                    help="--mode train: FSDP FULL_SHARD for the decoder layers (parameters sharded over the ranks, gathered per layer)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / fence / JSON plumbing only (gloo, no GPU, a sleep per step): the CPU test of --gpus N")
     ap.add_argument("--pipeline", type=int, default=7, choices=[1, 2, 7, 8],
@@ -246,7 +248,8 @@ def train_main(args, rank: int, world: int, dev, distributed: bool) -> None:
     B, L = args.batch, args.prompt_len + 8                # 32 prompt ids + 7 action ids + EOS (SURVEY §8d cfg 3 / 4)
     ts = TrainStep(w, args.stage, B, L, max_grad_norm=1.0 if lora is None else float("inf"),
                    weight_decay=0.0 if lora is None else 0.01, lora=lora, world=world, rank=rank,
-                   reduce_dtype=torch.float32 if args.reduce == "fp32" else torch.bfloat16, recompute=args.recompute)
+                   reduce_dtype=torch.float32 if args.reduce == "fp32" else torch.bfloat16, recompute=args.recompute,
+                   shard_params=args.shard_params)
     g = torch.Generator().manual_seed(100 + rank)         # each rank draws its own stream (base_strategy.py:259-266)
     ids = torch.randint(3, 31000, (B, L), generator=g)
     ids[:, 0] = 1
@@ -314,8 +317,9 @@ def train_main(args, rank: int, world: int, dev, distributed: bool) -> None:
                                     + (f"; optimizer state sharded over {world} ranks, {args.reduce} gradient reduce-scatter "
                                        f"per bucket overlapped with backward, bf16 weight all-gather" if world > 1 else "")),
                        "batch_per_gpu": B, "global_batch": B * world, "seq_len": ts.S, "stage": args.stage,
-                       "parallelism": f"dp{world} sharded-optimizer (shard-grad-op)" if world > 1 else "single GPU",
-                       "hip_graph": graph, "recompute_activations": bool(args.recompute)},
+                       "parallelism": (f"dp{world} sharded-optimizer ({'full-shard: decoder-layer parameters sharded' if args.shard_params else 'shard-grad-op'})"
+                                       if world > 1 else "single GPU"),
+                       "hip_graph": graph, "recompute_activations": bool(args.recompute), "shard_params": bool(args.shard_params)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "kernel": "tiled MFMA GEMM family (forward, dgrad, wgrad) per bl_gemm_bf16 call",

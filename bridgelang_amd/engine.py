@@ -41,7 +41,8 @@ def _fp8_layers(weights: VLAWeights) -> list:
 
 class OpenVLAEngine:
     def __init__(self, weights: VLAWeights, batch: int, prompt_len: int, n_new: int = 7, all_rows: bool = False,
-                 use_mask: bool = False, splitk: bool = False, fp8: bool = False, padded: bool = False):
+                 use_mask: bool = False, splitk: bool = False, fp8: bool = False, padded: bool = False,
+                 vision_only: bool = False):
         """all_rows=True builds the training/eval-style forward instead of generation: logits for every position
         (`logits_all` [B*S, vocab] fp32) and no decode steps. use_mask=True threads a [B, S] uint8 key-padding mask
         (`key_mask`, 1 = attend) through the Llama attention (modeling_prismatic.py:387-390). splitk=True lets
@@ -54,8 +55,11 @@ class OpenVLAEngine:
         the generation plan for a batch of RIGHT-PADDED prompts (`set_padded_inputs`; HF generation with an attention
         mask, modeling_prismatic.py:387-390): pad positions are hidden from every attention, each sequence's first token
         comes from ITS last real position, and the new tokens are rotated at the sequence's own position — every
-        sequence gets exactly the ids and logits it gets alone, un-padded (tests/test_hf_boundary_gpu.py)."""
+        sequence gets exactly the ids and logits it gets alone, un-padded (tests/test_hf_boundary_gpu.py).
+        vision_only=True plans the towers alone (the training step's frozen front end): no Llama plans, so nothing here
+        holds the decoder-layer weights (parameter-sharded training frees them)."""
         self.w, self.dims = weights, weights.dims
+        self.vision_only = vision_only
         self.padded = padded
         use_mask = use_mask or padded
         if padded and (all_rows or fp8):
@@ -89,14 +93,15 @@ class OpenVLAEngine:
         self.feats = z(B * 256, d.vision_dim)
         self.p1, self.p2 = z(B * 256, 4 * d.vision_dim), z(B * 256, D)
         # llm buffers
-        self.x = z(B, S, D)
-        self.h, self.ao = z(B * S, D), z(B * S, D)
-        self.qkv = z(B * S, 3 * D)
-        self.act = z(B * S, I)
-        self.k_cache = [z(B, d.llm_heads, self.cache_len, d.head_dim) for _ in range(d.llm_layers)]
-        self.v_cache = [z(B, d.llm_heads, self.cache_len, d.head_dim) for _ in range(d.llm_layers)]
-        self.xd, self.hd, self.aod = z(B, D), z(B, D), z(B, D)
-        self.qkvd, self.actd = z(B, 3 * D), z(B, I)
+        if not vision_only:
+            self.x = z(B, S, D)
+            self.h, self.ao = z(B * S, D), z(B * S, D)
+            self.qkv = z(B * S, 3 * D)
+            self.act = z(B * S, I)
+            self.k_cache = [z(B, d.llm_heads, self.cache_len, d.head_dim) for _ in range(d.llm_layers)]
+            self.v_cache = [z(B, d.llm_heads, self.cache_len, d.head_dim) for _ in range(d.llm_layers)]
+            self.xd, self.hd, self.aod = z(B, D), z(B, D), z(B, D)
+            self.qkvd, self.actd = z(B, 3 * D), z(B, I)
         self.cos, self.sin = rope_tables(d.head_dim, d.max_pos, d.rope_theta, dev)
         self.ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev) if splitk else None   # split-K scratch (opt-in)
         if padded:        # one mask over the whole cache: real prompt rows and every generated row are visible
@@ -123,9 +128,12 @@ class OpenVLAEngine:
         self.siglip_ops = self._plan_tower(weights.siglip, d.dino.dim, self.vbuf[1])
         self.vision_ops = self.dino_ops + self.siglip_ops      # serial order (profiling / single-stream use)
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        self.projector_ops = self._plan_projector()
-        self.prefill_ops = self._plan_prefill()
-        self.decode_ops = [self._plan_decode(t) for t in range(1, n_new)]
+        if vision_only:
+            self.projector_ops, self.prefill_ops, self.decode_ops = [], [], []
+        else:
+            self.projector_ops = self._plan_projector()
+            self.prefill_ops = self._plan_prefill()
+            self.decode_ops = [self._plan_decode(t) for t in range(1, n_new)]
         self._graph: Optional[torch.cuda.CUDAGraph] = None
 
     def _g(self, *args, **kw):

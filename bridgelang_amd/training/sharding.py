@@ -156,20 +156,35 @@ class ShardComm:
         if self.active:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
-    def all_gather_params(self, stage: torch.Tensor, b: Bucket) -> None:
-        """In place: every rank's updated bf16 slice of bucket b → the full bucket on every rank."""
+    def all_gather_params(self, full: torch.Tensor, b: Bucket) -> None:
+        """In place on `full` = the bf16 staging view of bucket b ([b.numel]): every rank's updated slice → the whole
+        bucket on every rank."""
         if not self.active:
             return
-        lo, hi = self.layout.shard_range(b)
-        full = stage[b.offset:b.offset + b.numel]
+        n = self.layout.shard_numel(b)
+        mine = full[self.layout.rank * n:(self.layout.rank + 1) * n]
         if self._native_rs:
-            dist.all_gather_into_tensor(full, stage[lo:hi], group=self.group)
+            dist.all_gather_into_tensor(full, mine, group=self.group)
         else:
-            parts = [torch.empty_like(stage[lo:hi]) for _ in range(self.layout.world)]
-            dist.all_gather(parts, stage[lo:hi].clone(), group=self.group)
+            parts = [torch.empty_like(mine) for _ in range(self.layout.world)]
+            dist.all_gather(parts, mine.clone(), group=self.group)
             for r, p in enumerate(parts):
-                a, e = self.layout.shard_range(b, r)
-                stage[a:e].copy_(p)
+                full[r * n:(r + 1) * n].copy_(p)
+
+    def all_gather_into(self, full: torch.Tensor, mine: torch.Tensor) -> None:
+        """Every rank's slice `mine` (equal sizes) → `full` (world × mine.numel()), rank order — the per-unit parameter
+        gather of parameter-sharded training (FSDP FULL_SHARD's pre-forward / pre-backward all-gather, fsdp.py:84-87)."""
+        n = mine.numel()
+        assert full.numel() == n * self.layout.world
+        if not self.active:
+            full.copy_(mine)
+        elif self._native_rs:
+            dist.all_gather_into_tensor(full, mine, group=self.group)
+        else:
+            parts = [torch.empty_like(mine) for _ in range(self.layout.world)]
+            dist.all_gather(parts, mine.contiguous(), group=self.group)
+            for r, p in enumerate(parts):
+                full[r * n:(r + 1) * n].copy_(p)
 
     def gather_full(self, local: torch.Tensor) -> torch.Tensor:
         """Shard-local buffer (layout.local_total) → full flat buffer (checkpointing the fp32 masters)."""

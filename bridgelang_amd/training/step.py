@@ -91,10 +91,13 @@ class ParamStore:
     copy on every rank, fp32 masters and AdamW moments for this rank's 1/world slice of every bucket only."""
 
     def __init__(self, w: VLAWeights, stage: str, world: int = 1, rank: int = 0,
-                 extra: Optional[List[Tuple[str, torch.Tensor, bool, str]]] = None, only: Optional[Sequence[str]] = None):
+                 extra: Optional[List[Tuple[str, torch.Tensor, bool, str]]] = None, only: Optional[Sequence[str]] = None,
+                 shard_params: bool = False):
         """`extra`: additional trainable bf16 tensors outside the model's own table — (name, flat live tensor, decayed,
         bucket key), e.g. LoRA adapters. `only`: restrict the stage's trainable set to these HF names (whole fused groups;
-        diagnostics / tests: optimizer state for a handful of tensors instead of the model)."""
+        diagnostics / tests: optimizer state for a handful of tensors instead of the model). `shard_params`: the
+        decoder-layer buckets keep NO full bf16 copy — each rank holds its 1/world slice (`own`), the unit is gathered
+        around its use (FSDP FULL_SHARD, fsdp.py:84-87; TrainStep(shard_params=True))."""
         self.w, self.stage = w, stage
         specs = w._specs()
         names = set(trainable_names(w, stage))
@@ -151,7 +154,19 @@ class ParamStore:
         self.n_params = sum(u.numel for u in self.units)
         dev = w.embed.device
         self.grad = torch.zeros(max(lay.total, 8), dtype=torch.float32, device=dev)
-        self.stage_bf16 = torch.zeros(max(lay.total, 8), dtype=torch.bfloat16, device=dev)
+        # bf16 staging copy of the updated parameters: every bucket but the parameter-sharded ones (a contiguous range
+        # [lo, hi) of the flat space, cut out of the staging buffer's addressing)
+        self.shard_params = shard_params
+        sh = [b for b in lay.buckets if shard_params and b.key.startswith("llm.layer")]
+        self.sharded_keys = {b.key for b in sh}
+        self._cut = (sh[0].offset, sh[-1].offset + sh[-1].numel) if sh else (lay.total, lay.total)
+        assert sum(b.numel for b in sh) == self._cut[1] - self._cut[0], "parameter-sharded buckets must be contiguous"
+        self.stage_bf16 = torch.zeros(max(lay.total - (self._cut[1] - self._cut[0]), 8), dtype=torch.bfloat16, device=dev)
+        self.own_off, n_own = {}, 0
+        for b in sh:
+            self.own_off[b.key] = n_own
+            n_own += lay.shard_numel(b)
+        self.own = torch.zeros(max(n_own, 8), dtype=torch.bfloat16, device=dev) if sh else None
         f = lambda: torch.zeros(max(lay.local_total, 8), dtype=torch.float32, device=dev)
         self.master, self.m, self.v = f(), f(), f()
         for bi, b in enumerate(lay.buckets):                    # masters ← this rank's slice of the live bf16 weights
@@ -166,6 +181,8 @@ class ParamStore:
             lo, hi = lay.shard_range(b)
             lo_l = lay.local_offset(b)
             self.master[lo_l:lo_l + hi - lo].copy_(full[lo - b.offset:hi - b.offset])
+            if b.key in self.sharded_keys:
+                self.own_slice(b).copy_(full[lo - b.offset:hi - b.offset])
             del full
         self.blocks_per_bucket = 2048
         self.partial = torch.zeros(self.blocks_per_bucket * max(len(lay.buckets), 1), dtype=torch.float32, device=dev)
@@ -173,6 +190,18 @@ class ParamStore:
         self.step_count = 0
 
     # ---- views ----
+    def stage_view(self, offset: int, numel: int) -> torch.Tensor:
+        """bf16 staging view of flat range [offset, offset + numel) (never inside the parameter-sharded range)."""
+        lo, hi = self._cut
+        assert offset + numel <= lo or offset >= hi, "no staging copy exists for parameter-sharded buckets"
+        o = offset if offset < lo else offset - (hi - lo)
+        return self.stage_bf16[o:o + numel]
+
+    def own_slice(self, b) -> torch.Tensor:
+        """This rank's bf16 slice of a parameter-sharded bucket."""
+        o = self.own_off[b.key]
+        return self.own[o:o + self.layout.shard_numel(b)]
+
     def grad_view(self, name_or_unit) -> torch.Tensor:
         """fp32 gradient of a unit: [n, k] for a group, flat for a plain tensor."""
         u = name_or_unit if isinstance(name_or_unit, Unit) else self.by_name[name_or_unit]
@@ -228,14 +257,18 @@ class TrainStep:
     def __init__(self, weights: VLAWeights, stage: str, batch: int, prompt_len: int, *, max_grad_norm: float = 1.0,
                  weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8, store: Optional[ParamStore] = None,
                  world: int = 1, rank: int = 0, group=None, reduce_dtype: torch.dtype = torch.float32, lora=None,
-                 force_comm: bool = False, recompute: bool = False):
+                 force_comm: bool = False, recompute: bool = False, shard_params: bool = False):
         """`lora`: a training.lora.LoraAdapters → stage "lora": the base model is frozen and only the adapters train.
-        `recompute`: keep only each decoder layer's input and replay its forward inside the backward pass."""
+        `recompute`: keep only each decoder layer's input and replay its forward inside the backward pass.
+        `shard_params`: FSDP FULL_SHARD for the decoder layers (fsdp.py:84-87) — every rank keeps 1/world of each layer's
+        bf16 weights; a layer is all-gathered into one of two slots (and packed into the forward / dgrad layouts there) one
+        layer ahead of its forward and again ahead of its backward, on the communication stream; AdamW updates the
+        rank's slice in place. The model's own decoder-layer allocation is freed (`materialize_params()` brings it back)."""
         if (lora is not None) != (stage == "lora"):
             raise ValueError("stage 'lora' and the `lora` adapters go together")
-        if recompute and lora is not None:
-            raise ValueError("activation recomputation is planned for the full-parameter stages only")
-        self.recompute = recompute
+        if (recompute or shard_params) and lora is not None:
+            raise ValueError("activation recomputation / parameter sharding are planned for the full-parameter stages only")
+        self.recompute, self.shard_params = recompute, shard_params
         self.lora = lora
         self.train_vision = STAGES[stage][0] or lora is not None      # towers need their training-form forward
         self.w, self.dims, self.stage = weights, weights.dims, stage
@@ -245,14 +278,21 @@ class TrainStep:
             raise ValueError("training sequences are limited to 320 positions (whole-sequence attention kernels)")
         self.max_grad_norm, self.weight_decay, self.betas, self.eps = max_grad_norm, weight_decay, betas, eps
         if store is None:
-            store = ParamStore(weights, stage, world, rank, extra=lora.plain_units() if lora is not None else None)
+            store = ParamStore(weights, stage, world, rank, extra=lora.plain_units() if lora is not None else None,
+                               shard_params=shard_params)
         self.store = store
-        assert self.store.stage == stage
+        assert self.store.stage == stage and self.store.shard_params == shard_params
+        shard_params = self.shard_params = shard_params and bool(self.store.sharded_keys)      # frozen LLM: nothing to shard
         st = self.store
         self.comm = ShardComm(st.layout, group, reduce_dtype, force=force_comm)
         self.world = st.layout.world
         dev = weights.embed.device
         self.device = dev
+        self._wT: Dict[int, torch.Tensor] = {}       # transposed packed weights for dgrad
+        self._cur_layer = -1                   # decoder layer whose ops are being planned (slot tensors are shared by layers)
+        self._materialized = False
+        if shard_params:                       # first: the model's layer allocation is given back before anything else is reserved
+            self._setup_param_shards()
         B, S, D, I, V, NL = batch, self.S, d.llm_dim, d.llm_inter, d.vocab, d.llm_layers
         Tn = B * S
         self.T, self.Tp = Tn, (Tn + 63) // 64 * 64
@@ -279,7 +319,7 @@ class TrainStep:
         # ---- frozen vision front end: reuse the inference engine's tower plans (its LLM buffers are not allocated twice:
         #      prompt_len 1, no decode) ----
         from ..engine import OpenVLAEngine
-        self._vis = OpenVLAEngine(weights, batch, 1, n_new=1)
+        self._vis = OpenVLAEngine(weights, batch, 1, n_new=1, vision_only=True)
         self.pixel_values = self._vis.pixel_values
         self.feats = self._vis.feats if lora is None else za(B * 256, d.vision_dim, R_(weights.fc1_w))
         # ---- saved activations ----
@@ -331,7 +371,6 @@ class TrainStep:
         self.dfeats = z(B * 256, d.vision_dim) if self.train_vision else None
         self.vis = [self._alloc_tower(tw) for tw in towers]
         # ---- transposed weights for dgrad ----
-        self._wT: Dict[int, torch.Tensor] = {}
         self.ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
         if lora is not None:
             self._build_extended_weights()
@@ -344,9 +383,105 @@ class TrainStep:
         self.backward_ops = self._plan_backward()
         self.repack_ops = self._plan_repack()
         self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
-        self._comm_stream = torch.cuda.Stream(device=dev) if self.comm.active else None
+        self._comm_stream = torch.cuda.Stream(device=dev) if (self.comm.active or shard_params) else None
+        self._rs_scratch = (z(self._slots[0]["flat"].numel()) if shard_params and self.comm.active
+                            and reduce_dtype != torch.float32 else None)        # bf16 wire copy of one layer's gradients
 
     # ---- helpers ------------------------------------------------------------------------------------------------
+    # ---- parameter sharding (FSDP FULL_SHARD for the decoder layers) ---------------------------------------------------
+    _LAYER_KEYS = ("qkv_w", "o_w", "gu_w", "down_w")
+
+    def _setup_param_shards(self) -> None:
+        """Two gather slots (logical bf16 bucket + the four packed forward weights + their transposed dgrad copies); every
+        decoder layer's weight tensors are re-pointed at slot l % 2 and the model's own layer allocation is freed."""
+        w, st, lay, dev = self.w, self.store, self.store.layout, self.device
+        by_group = {id(u.group): u for u in st.units if u.group is not None}
+        self._layer_units: Dict[Tuple[int, str], Unit] = {
+            (l, key): by_group[id(w.groups[gi])] for l, key, gi, _ in w._layer_views if id(w.groups[gi]) in by_group}
+        self._sharded_layers = sorted({l for l, _ in self._layer_units})
+        sizes = {lay.buckets[self._layer_units[(l, "qkv_w")].bucket].numel for l in self._sharded_layers}
+        assert len(sizes) == 1 and len(self._layer_units) == 4 * len(self._sharded_layers), "decoder layers are uniform units"
+        bucket_numel = next(iter(sizes))
+        L0 = w.layers[0]
+        self._slots: List[dict] = []
+        for _ in range(2):
+            slot = {"flat": torch.zeros(bucket_numel, dtype=torch.bfloat16, device=dev)}
+            for key in self._LAYER_KEYS:
+                p = getattr(L0, key)
+                slot[key] = torch.zeros(tuple(p.shape), dtype=torch.bfloat16, device=dev)
+                slot[key + "T"] = torch.zeros(p.shape[1] * 2, p.shape[0] // 2, 64, 8, dtype=torch.bfloat16, device=dev)
+            slot["ready"], slot["free"] = torch.cuda.Event(), torch.cuda.Event()
+            self._slots.append(slot)
+        self._slot_key = {slot[k].data_ptr(): k for slot in self._slots for k in self._LAYER_KEYS}
+        for slot in self._slots:
+            for k in self._LAYER_KEYS:
+                self._wT[slot[k].data_ptr()] = slot[k + "T"]
+        if len(self._sharded_layers) != self.dims.llm_layers:
+            raise ValueError("parameter sharding needs every decoder layer trainable (vla-full-train / vla-train)")
+        if w.layers_resident:
+            w.release_layer_weights(self._slots)
+        else:                                  # re-planned step over an already sharded model
+            w.repoint_layer_weights(self._slots)
+        # per-layer prepared pack ops: logical [n, k] rows of the gathered bucket → forward and dgrad layouts of the slot
+        self._pack_ops: Dict[int, Tuple[List[Op], List[Op]]] = {}          # layer → (forward pass, backward pass)
+        for l in self._sharded_layers:
+            slot = self._slots[l % 2]
+            b = lay.buckets[self._layer_units[(l, "qkv_w")].bucket]
+            fwd, bwd = [], []
+            for key in self._LAYER_KEYS:
+                u = self._layer_units[(l, key)]
+                rm = slot["flat"][u.offset - b.offset:u.offset - b.offset + u.numel].view(u.group.n, u.group.k)
+                fwd.append(T.pack(rm, slot[key], run=False))                              # forward operand layout
+                bwd.append(T.transpose_pack(rm, slot[key + "T"], u.group.n, run=False))   # dgrad operand layout
+            self._pack_ops[l] = (fwd, bwd + fwd if self.recompute else bwd)
+
+    def _layer_bucket(self, l: int):
+        return self.store.layout.buckets[self._layer_units[(l, "qkv_w")].bucket]
+
+    def _gather_ops(self, l: int, backward: bool = False) -> Op:
+        """Issue layer l's parameter gather + packing on the communication stream (runs ahead of the compute stream)."""
+        def fn():
+            slot, side = self._slots[l % 2], self._comm_stream
+            side.wait_event(slot["free"])                     # the layer that used this slot before is done with it
+            with torch.cuda.stream(side):
+                b = self._layer_bucket(l)
+                self.comm.all_gather_into(slot["flat"][:b.numel], self.store.own_slice(b))
+                ops.run_all(self._pack_ops[l][1 if backward else 0])
+                slot["ready"].record(side)
+        return ops.glue("gather_layer_params", fn, ())
+
+    def _await_ops(self, l: int) -> Op:
+        return ops.glue("await_layer_params", lambda: torch.cuda.current_stream().wait_event(self._slots[l % 2]["ready"]), ())
+
+    def _release_ops(self, l: int) -> Op:
+        return ops.glue("release_layer_params", lambda: self._slots[l % 2]["free"].record(torch.cuda.current_stream()), ())
+
+    def _unit_of(self, packed: torch.Tensor) -> Optional[Unit]:
+        if self.shard_params and packed.data_ptr() in self._slot_key:
+            assert self._cur_layer >= 0, "slot weights are only addressed while a decoder layer is being planned"
+            return self._layer_units[(self._cur_layer, self._slot_key[packed.data_ptr()])]
+        return self.store.unit_of_packed(packed)
+
+    def materialize_params(self) -> None:
+        """Bring the decoder layers back into the model's own allocation (gather every layer, pack) — for inference,
+        `state_dict()` / `save_pretrained` after parameter-sharded training. The step's plans address the slots, so this
+        step object cannot train afterwards."""
+        if not self.shard_params or self._materialized:
+            return
+        torch.cuda.synchronize()
+        w, st = self.w, self.store
+        w.restore_layer_weights()
+        slot = self._slots[0]
+        for l in self._sharded_layers:
+            b = self._layer_bucket(l)
+            self.comm.all_gather_into(slot["flat"][:b.numel], st.own_slice(b))
+            for key in self._LAYER_KEYS:
+                u = self._layer_units[(l, key)]
+                rm = slot["flat"][u.offset - b.offset:u.offset - b.offset + u.numel].view(u.group.n, u.group.k)
+                T.pack(rm, getattr(w.layers[l], key))
+        torch.cuda.synchronize()
+        self._materialized = True
+
     def _g(self, *a, **k) -> Op:
         """Prepared GEMM with the split-K scratch: training has no batch-slot invariance to keep (engine.py keeps it
         off for inference), so ragged last rounds of K >= 8192 GEMMs are split along K."""
@@ -384,7 +519,7 @@ class TrainStep:
 
     def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, packed: torch.Tensor) -> List[Op]:
         """Weight gradient of a base linear; [] when the weight is frozen."""
-        u = self.store.unit_of_packed(packed)
+        u = self._unit_of(packed)
         return [] if u is None else self._wgrad_into(dy, x, self.store.grad_view(u))
 
     def _build_extended_weights(self) -> None:
@@ -469,8 +604,17 @@ class TrainStep:
         plan += lin(self.p2, w.fc3_w, self.p3, EPI_BIAS, bias=w.fc3_b)
         plan += [T.map_rows(self.p3, self.x[0], rows=B * 256, group=256, stride=S, offset=1, scatter=True, run=False),
                  ops.embed_splice(self.input_ids, w.embed, self.x[0].view(B, S, D), d.n_patches, run=False)]
-        for l in range(d.llm_layers):
+        NL = d.llm_layers
+        if self.shard_params:
+            plan.append(self._gather_ops(0))
+        for l in range(NL):
+            if self.shard_params:          # this layer's weights have landed; the next layer's gather runs under its compute
+                plan.append(self._await_ops(l))
+                if l + 1 < NL:
+                    plan.append(self._gather_ops(l + 1))
             plan += self._layer_forward(l)
+            if self.shard_params:
+                plan.append(self._release_ops(l))
         plan += [ops.rmsnorm(self.x[-1], w.norm, self.hn, d.rms_eps, run=False),
                  g(self.hn, w.lm_head, self.logits, EPI_F32_BF16R),
                  ops.cross_entropy(self.logits, self.targets, self.row_loss, self.mean_cnt, IGNORE_INDEX, run=False)]
@@ -513,8 +657,15 @@ class TrainStep:
         assert self.dqkv.stride(0) == lq and self.dao.stride(0) == lo
         strides, so = (S * lq, hd, lq), (S * lo, hd, lo)
         stop_layer = self._lowest_needed_layer()
+        if self.shard_params:
+            plan.append(self._gather_ops(d.llm_layers - 1, backward=True))
         for l in range(d.llm_layers - 1, stop_layer - 1, -1):
             lw, b = w.layers[l], f"{lm}.layers.{l}"
+            self._cur_layer = l
+            if self.shard_params:
+                plan.append(self._await_ops(l))
+                if l - 1 >= stop_layer:
+                    plan.append(self._gather_ops(l - 1, backward=True))
             if self.recompute:         # incl. the top layer: the plan stays idempotent (graph capture runs it twice)
                 plan += self._layer_forward(l, with_down=False)
             plan += lb(dx, self.act[l], lw.down_w, self.dact)
@@ -530,9 +681,12 @@ class TrainStep:
                                              o_strides=so, causal=True, key_mask=self.key_mask, run=False))
             plan.append(T.rope_backward(dq, self.cos, self.sin, B=B, S=S, H=H, head_dim=hd, run=False))
             plan += lb(dq, self.h1[l], lw.qkv_w, self.dh)
+            if self.shard_params:
+                plan.append(self._release_ops(l))
             self._ready.append((len(plan), f"llm.layer{l:02d}"))
             plan.append(T.rmsnorm_backward(self.x[l], lw.ln1, self.dh, dx, self._gvec(f"{b}.input_layernorm.weight", D),
                                            self.norm_ws, d.rms_eps, dres=dx2, run=False))
+        self._cur_layer = -1
         if stop_layer > 0:
             return plan
         # dx = gradient of inputs_embeds [B, S, D]
@@ -689,12 +843,12 @@ class TrainStep:
         st = self.store
         nmax = max((u.numel for u in st.units), default=8)
         self._tW = torch.zeros(nmax, dtype=torch.bfloat16, device=self.device)
-        self._plain_copies = [(u.dst, st.stage_bf16[u.offset:u.offset + u.numel]) for u in st.units if u.group is None]
+        self._plain_copies = [(u.dst, st.stage_view(u.offset, u.numel)) for u in st.units if u.group is None]
         for u in st.units:
-            if u.group is None:
-                continue
+            if u.group is None or st.layout.buckets[u.bucket].key in st.sharded_keys:
+                continue                                          # parameter-sharded layers are packed when gathered
             n, k = u.group.n, u.group.k
-            rm = st.stage_bf16[u.offset:u.offset + u.numel].view(n, k)
+            rm = st.stage_view(u.offset, u.numel).view(n, k)
             plan.append(T.pack(rm, u.group.packed, run=False))
             key = u.group.packed.data_ptr()
             if key in self._wT:                                   # only weights that a dgrad GEMM actually reads
@@ -730,7 +884,9 @@ class TrainStep:
         self.targets.copy_(tg.view(-1))
 
     def _replay(self, key: str, plan: List[Op], graph: bool) -> None:
-        if not graph:
+        if self._materialized:
+            raise RuntimeError("materialize_params() ended this step object's training (its plans address the gather slots)")
+        if not graph or (self.shard_params and key in ("fwd", "bwd")):      # per-layer collectives stay out of HIP graphs
             ops.run_all(plan)
             return
         gr = self._graphs.get(key)
@@ -769,7 +925,11 @@ class TrainStep:
             ev.record(main)
             self._comm_stream.wait_event(ev)
             with torch.cuda.stream(self._comm_stream):
-                self.comm.reduce_scatter_grads(st.grad, b, st.stage_bf16[b.offset:b.offset + b.numel])
+                if b.key in st.sharded_keys:
+                    scratch = self._rs_scratch[:b.numel] if self._rs_scratch is not None else None
+                else:
+                    scratch = st.stage_view(b.offset, b.numel)
+                self.comm.reduce_scatter_grads(st.grad, b, scratch)
             reduced.add(b.key)
         for upto, key in self._ready:
             ops.run_all(self.backward_ops[done:upto])
@@ -818,14 +978,16 @@ class TrainStep:
             b = lay.buckets[i]
             lo, hi = lay.shard_range(b)
             sl = slice(lay.local_offset(b), lay.local_offset(b) + hi - lo)
+            sharded = b.key in st.sharded_keys                     # parameter-sharded: the rank's bf16 slice IS the parameter
             T.adamw(st.master[sl], st.m[sl], st.v[sl], st.grad[lo:hi], st.step_count, lr, betas=self.betas, eps=self.eps,
-                    weight_decay=self.weight_decay if b.decay else 0.0, norm_coef=st.norm_coef, p_bf16=st.stage_bf16[lo:hi])
-            if self.comm.active:                                   # gather bucket i while AdamW runs on bucket i+1
+                    weight_decay=self.weight_decay if b.decay else 0.0, norm_coef=st.norm_coef,
+                    p_bf16=st.own_slice(b) if sharded else st.stage_view(lo, hi - lo))
+            if self.comm.active and not sharded:                   # gather bucket i while AdamW runs on bucket i+1
                 ev = torch.cuda.Event()
                 ev.record(main)
                 self._comm_stream.wait_event(ev)
                 with torch.cuda.stream(self._comm_stream):
-                    self.comm.all_gather_params(st.stage_bf16, b)
+                    self.comm.all_gather_params(st.stage_view(b.offset, b.numel), b)
         if self.comm.active:
             main.wait_stream(self._comm_stream)
         for dst, src in self._plain_copies:

@@ -165,6 +165,10 @@ class ShardedOptimizerStrategy:
                                                       ("llm_backbone", llm != "none")) if on]
         self.all_module_keys = list(self.ALL_MODULE_KEYS)
         self.max_text_len = max_text_len
+        # "full-shard" (FSDP FULL_SHARD, fsdp.py:84-87): the decoder layers' parameters are sharded over the ranks and
+        # gathered per layer around their use (TrainStep(shard_params=True)) in the stages that train the whole LLM; the
+        # other stages, and "shard-grad-op", keep the bf16 weights replicated and shard gradients + optimizer state
+        self.shard_params = sharding_strategy == "full-shard" and STAGES[stage][2] == "all"
         # the reference checkpoints every decoder layer when `enable_gradient_checkpointing` (fsdp.py:171-183) because
         # 80 GB parts cannot keep the activations; here they stay resident unless they would not fit (None = decide from
         # free HBM when the step is planned), and True / False force either form
@@ -182,7 +186,10 @@ class ShardedOptimizerStrategy:
         lr_at(0, self.learning_rate, self.lr_scheduler_type, 1, 0)          # validates the schedule name
         self.num_warmup_steps = (int(self.num_training_steps * self.warmup_ratio)
                                  if self.lr_scheduler_type == "linear-warmup+cosine-decay" else 0)
-        self.store = ParamStore(self.vlm.weights, self.stage, self.world, self.rank)
+        if self.shard_params:           # inference engines cached on the model hold the decoder-layer weights: drop them
+            for cache in ("_engines", "_forward_engines"):
+                getattr(self.vlm, cache, {}).clear()
+        self.store = ParamStore(self.vlm.weights, self.stage, self.world, self.rank, shard_params=self.shard_params)
         self._ensure_engine(self.max_text_len)
 
     def _ensure_engine(self, text_len: int) -> TrainStep:
@@ -195,6 +202,7 @@ class ShardedOptimizerStrategy:
             self.step_engine = TrainStep(
                 self.vlm.weights, self.stage, self.per_device_batch_size, L, max_grad_norm=self.max_grad_norm,
                 weight_decay=self.weight_decay, store=self.store, recompute=self._want_recompute(L),
+                shard_params=self.shard_params, world=self.world, rank=self.rank,
                 reduce_dtype=torch.float32 if self.reduce_in_full_precision else torch.bfloat16)
         return self.step_engine
 
@@ -288,12 +296,20 @@ class ShardedOptimizerStrategy:
                 if dist.is_initialized():
                     dist.barrier()
                 if terminate:
+                    self.finish()
                     return
+        self.finish()
+
+    def finish(self) -> None:
+        """End of training: a parameter-sharded run gathers the decoder layers back into the model's own allocation, so
+        `vlm` is whole again for inference / `save_pretrained` (collective: every rank calls it)."""
+        if self.step_engine is not None:
+            self.step_engine.materialize_params()
 
 
 def get_train_strategy(train_strategy: str, **kwargs) -> ShardedOptimizerStrategy:
-    """prismatic/training/materialize.py:get_train_strategy: both FSDP ids map onto the sharded-optimizer strategy (the
-    parameters themselves stay replicated on 288 GB parts, which is `shard-grad-op` behaviour for either id)."""
+    """prismatic/training/materialize.py:get_train_strategy: "fsdp-shard-grad-op" shards gradients + optimizer state under
+    replicated bf16 weights; "fsdp-full-shard" additionally shards the decoder layers' parameters (gathered per layer)."""
     if train_strategy not in ("fsdp-shard-grad-op", "fsdp-full-shard"):
         raise ValueError(f"Train Strategy `{train_strategy}` is not supported!")
     return ShardedOptimizerStrategy(sharding_strategy=train_strategy[len("fsdp-"):], **kwargs)

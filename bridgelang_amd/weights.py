@@ -364,6 +364,43 @@ class VLAWeights:
     placements: Dict[str, Placement] = field(default_factory=dict)
     groups: List[PackedGroup] = field(default_factory=list)
     passthrough: Dict[str, torch.Tensor] = field(default_factory=dict)   # passthrough_specs(): stored, never executed
+    layer_arena: Optional[Arena] = None      # the decoder layers' GEMM weights: a second allocation that parameter-sharded
+                                             # training can give back (release_layer_weights)
+    _layer_views: List[tuple] = field(default_factory=list)             # (layer index, field, group index, arena view index)
+
+    # ---- parameter-sharded training (training/step.py, shard_params): decoder-layer GEMM weights leave the device -------
+    @property
+    def layers_resident(self) -> bool:
+        return self.layer_arena is not None and self.layer_arena.buf is not None
+
+    def repoint_layer_weights(self, slots: List[Dict[str, torch.Tensor]]) -> None:
+        """Point every decoder layer's packed GEMM weights (and their PackedGroups) at the gather slots: layer l uses
+        slots[l % len(slots)]."""
+        self.__dict__.pop("_fp8_layers", None)
+        for l, key, gi, _ in self._layer_views:
+            t = slots[l % len(slots)][key]
+            assert tuple(t.shape) == tuple(getattr(self.layers[l], key).shape), (l, key)
+            setattr(self.layers[l], key, t)
+            self.groups[gi].packed = t
+
+    def release_layer_weights(self, slots: List[Dict[str, torch.Tensor]]) -> int:
+        """repoint_layer_weights + free the layers' allocation. Returns the bytes given back. Anything that still holds
+        the old views (engine plans built before the call) keeps the storage alive: callers drop those first."""
+        if not self.layers_resident:
+            raise RuntimeError("decoder-layer weights are not resident")
+        self.repoint_layer_weights(slots)
+        self.layer_arena.buf = None
+        return self.layer_arena.nbytes
+
+    def restore_layer_weights(self) -> None:
+        """Re-allocate the decoder layers' GEMM weights (zero-filled; the caller gathers and packs them)."""
+        if self.layers_resident:
+            return
+        self.layer_arena.commit()
+        for l, key, gi, idx in self._layer_views:
+            t = self.layer_arena.view(idx)
+            setattr(self.layers[l], key, t)
+            self.groups[gi].packed = t
 
     def _specs(self, recipe: str = "init") -> Dict[str, TensorSpec]:
         return {s.name: s for s in tensor_specs(self.dims, recipe)}
@@ -450,7 +487,10 @@ def allocate(dims: VLADims, device: torch.device | str = "cuda") -> VLAWeights:
     """Reserve the arena and build the name → placement table. Tensors are zero until filled."""
     device = torch.device(device)
     arena = Arena(device)
+    layer_arena = Arena(device)                  # decoder-layer GEMM weights (see VLAWeights.release_layer_weights)
+    layer_views: List[tuple] = []
     pending: List[Tuple[int, Callable[[torch.Tensor], None]]] = []
+    pending_layers: List[Tuple[int, Callable[[torch.Tensor], None]]] = []
     plain: Dict[str, tuple] = {}                 # name → (holder, key, offset, rows, cols, ld)
     grouped: Dict[str, tuple] = {}               # name → (group id, offset, rows, cols, ld)
     group_defs: List[tuple] = []                 # (holder, key, n, k)
@@ -458,9 +498,15 @@ def allocate(dims: VLADims, device: torch.device | str = "cuda") -> VLAWeights:
     def dense(holder, key, shape):
         pending.append((arena.reserve(tuple(shape)), lambda x, h=holder, k=key: h.__setitem__(k, x)))
 
-    def gemm_w(holder, key, n, k) -> int:
+    def gemm_w(holder, key, n, k, layer: Optional[int] = None) -> int:
         assert n % 16 == 0 and k % 64 == 0, (key, n, k)
-        pending.append((arena.reserve((n // 16, k // 32, 64, 8)), lambda x, h=holder, kk=key: h.__setitem__(kk, x)))
+        setter = lambda x, h=holder, kk=key: h.__setitem__(kk, x)
+        if layer is None:
+            pending.append((arena.reserve((n // 16, k // 32, 64, 8)), setter))
+        else:
+            idx = layer_arena.reserve((n // 16, k // 32, 64, 8))
+            pending_layers.append((idx, setter))
+            layer_views.append((layer, key, len(group_defs), idx))
         group_defs.append((holder, key, n, k))
         return len(group_defs) - 1
 
@@ -510,20 +556,23 @@ def allocate(dims: VLADims, device: torch.device | str = "cuda") -> VLAWeights:
         bn = f"{lm}.layers.{i}"
         dense(lh, "ln1", (L,)); plain[f"{bn}.input_layernorm.weight"] = (lh, "ln1", 0, 1, L, L)
         dense(lh, "ln2", (L,)); plain[f"{bn}.post_attention_layernorm.weight"] = (lh, "ln2", 0, 1, L, L)
-        g = gemm_w(lh, "qkv_w", 3 * L, L)
+        g = gemm_w(lh, "qkv_w", 3 * L, L, layer=i)
         for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
             grouped[f"{bn}.self_attn.{n}.weight"] = (g, j * L * L, L, L, L)
-        g = gemm_w(lh, "o_w", L, L); grouped[f"{bn}.self_attn.o_proj.weight"] = (g, 0, L, L, L)
-        g = gemm_w(lh, "gu_w", 2 * I, L)
+        g = gemm_w(lh, "o_w", L, L, layer=i); grouped[f"{bn}.self_attn.o_proj.weight"] = (g, 0, L, L, L)
+        g = gemm_w(lh, "gu_w", 2 * I, L, layer=i)
         grouped[f"{bn}.mlp.gate_proj.weight"] = (g, 0, I, L, 2 * L)      # row 2j   = gate_j
         grouped[f"{bn}.mlp.up_proj.weight"] = (g, L, I, L, 2 * L)        # row 2j+1 = up_j
-        g = gemm_w(lh, "down_w", L, I); grouped[f"{bn}.mlp.down_proj.weight"] = (g, 0, L, I, I)
+        g = gemm_w(lh, "down_w", L, I, layer=i); grouped[f"{bn}.mlp.down_proj.weight"] = (g, 0, L, I, I)
     dense(top, "norm", (L,)); plain[f"{lm}.norm.weight"] = (top, "norm", 0, 1, L, L)
     g = gemm_w(top, "lm_head", dims.vocab, L); grouped["language_model.lm_head.weight"] = (g, 0, dims.vocab, L, L)
 
     arena.commit()
+    layer_arena.commit()
     for idx, setter in pending:
         setter(arena.view(idx))
+    for idx, setter in pending_layers:
+        setter(layer_arena.view(idx))
 
     def mk_tower(t: TowerDims, h: dict) -> TowerW:
         return TowerW(t, h["patch_w"], h["patch_b"], h["pos"], h["prefix"], [BlockW(**b) for b in h["blocks"]])
@@ -531,6 +580,7 @@ def allocate(dims: VLADims, device: torch.device | str = "cuda") -> VLAWeights:
     w = VLAWeights(dims, arena, mk_tower(dims.dino, hd), mk_tower(dims.siglip, hs),
                    top["fc1_w"], top["fc1_b"], top["fc2_w"], top["fc2_b"], top["fc3_w"], top["fc3_b"], top["embed"],
                    [LayerW(**lh) for lh in layer_h], top["norm"], top["lm_head"])
+    w.layer_arena, w._layer_views = layer_arena, layer_views
     w.groups = [PackedGroup(holder[key], n, k) for holder, key, n, k in group_defs]
     for name, (holder, key, off, rows, cols, ld) in plain.items():
         w.placements[name] = Placement(holder[key], off, rows, cols, ld)

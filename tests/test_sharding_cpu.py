@@ -98,7 +98,7 @@ for step in (1, 2):
         sl = slice(lay.local_offset(b), lay.local_offset(b) + hi - lo)
         adamw(master[sl], m[sl], v[sl], grad[lo:hi], step, 1e-2, 0.1 if b.decay else 0.0, coef)
         stage[lo:hi] = master[sl].to(torch.bfloat16)
-        comm.all_gather_params(stage, b)
+        comm.all_gather_params(stage[b.offset:b.offset + b.numel], b)
     # single-process reference on the averaged gradients
     if reduce_dtype == torch.bfloat16:
         avg = sum((g / world).to(torch.bfloat16).float() for g in grads)      # bf16 wire format, fp32 accumulate ≈

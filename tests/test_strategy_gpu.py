@@ -26,7 +26,10 @@ class Repeat(torch.utils.data.IterableDataset):
             yield s
 
 
-def test_run_vla_training_overfits_and_checkpoints(dev, tmp_path):
+@pytest.mark.parametrize("train_strategy", ["fsdp-shard-grad-op", "fsdp-full-shard"])
+def test_run_vla_training_overfits_and_checkpoints(dev, tmp_path, train_strategy):
+    """`fsdp-full-shard`: the decoder layers' parameters are sharded (gathered per layer around their use, the model's
+    own layer allocation freed during training, gathered back by `finish()`); everything observable stays the same."""
     from bridgelang_amd import weights as W
     from bridgelang_amd.extern.hf.configuration_prismatic import OpenVLAConfig
     from bridgelang_amd.extern.hf.modeling_prismatic import OpenVLAForActionPrediction
@@ -44,13 +47,15 @@ def test_run_vla_training_overfits_and_checkpoints(dev, tmp_path):
     B, steps = 4, 12
     data = Repeat(ds, n_samples=4, n_batches=steps, batch=B)
     collator = PaddedCollatorForActionPrediction(2048, tok.pad_token_id, padding_side="right")
-    strat = get_train_strategy("fsdp-shard-grad-op", vlm=vlm, device_id=0, stage="vla-train", epochs=1, max_steps=steps,
+    strat = get_train_strategy(train_strategy, vlm=vlm, device_id=0, stage="vla-train", epochs=1, max_steps=steps,
                                global_batch_size=B, per_device_batch_size=B, learning_rate=1e-3, weight_decay=0.0,
                                max_grad_norm=1.0, lr_scheduler_type="constant", warmup_ratio=0.0, max_text_len=8)
-    strat.run_setup(tmp_path, n_train_examples=len(data))
-    metrics = VLAMetrics(("jsonl",), "run0", tmp_path, {"lr": 1e-3})
     before = {k: v.float().cpu() for k, v in vlm.state_dict().items()}
+    strat.run_setup(tmp_path, n_train_examples=len(data))
+    assert vlm.weights.layers_resident == (train_strategy != "fsdp-full-shard")
+    metrics = VLAMetrics(("jsonl",), "run0", tmp_path, {"lr": 1e-3})
     strat.run_vla_training(data, collator, at, metrics, save_interval=1000, save_full_model=False)
+    assert vlm.weights.layers_resident                      # finish() brought a sharded model back
     rows = [json.loads(l) for l in open(tmp_path / "run0.jsonl")]
     losses = [r["VLA Train/Loss"] for r in rows]
     print("losses", [round(x, 3) for x in losses], "acc", [round(r["VLA Train/Action Token Accuracy"], 2) for r in rows])

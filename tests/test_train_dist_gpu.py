@@ -29,16 +29,30 @@ dims = tiny_dims()
 w = allocate(dims, dev).fill_synthetic(seed=3)
 B, L = 4, 20
 rd = torch.bfloat16 if os.environ.get("BL_REDUCE") == "bf16" else torch.float32
-ts = TrainStep(w, "vla-train", B // world, L, max_grad_norm=1.0, weight_decay=0.1, world=world, rank=rank, reduce_dtype=rd)
-out = []
-for step in range(2):
-    ids, mask, labels, pv = make_batch(dims, B, L, seed=20 + step, ragged=False)
-    sl = slice(rank * B // world, (rank + 1) * B // world)
-    ts.set_batch(ids[sl], mask[sl], pv[sl], labels[sl])
-    loss, norm = ts.step(1e-3)
-    out.append((loss.item(), norm.item()))
+def run(w, shard_params):
+    ts = TrainStep(w, "vla-train", B // world, L, max_grad_norm=1.0, weight_decay=0.1, world=world, rank=rank, reduce_dtype=rd,
+                   shard_params=shard_params)
+    out = []
+    for step in range(2):
+        ids, mask, labels, pv = make_batch(dims, B, L, seed=20 + step, ragged=False)
+        sl = slice(rank * B // world, (rank + 1) * B // world)
+        ts.set_batch(ids[sl], mask[sl], pv[sl], labels[sl])
+        loss, norm = ts.step(1e-3)
+        out.append((loss.item(), norm.item()))
+    return ts, out
+ts, out = run(w, False)
 sd = ts.store.master_state_dict(ts.comm)
 live = {k: v.cpu() for k, v in w.state_dict().items()}
+# FULL_SHARD over two ranks: each rank keeps half of every decoder layer; results equal the replicated-weight run exactly
+w2 = allocate(dims, dev).fill_synthetic(seed=3)
+ts2, out2 = run(w2, True)
+assert not w2.layers_resident and ts2.store.own.numel() * world <= sum(b.numel for b in ts2.store.layout.buckets if b.key.startswith("llm.layer")) + 8
+assert out2 == out, (out, out2)
+sd2 = ts2.store.master_state_dict(ts2.comm)
+assert all(torch.equal(sd[k], sd2[k]) for k in sd)
+ts2.materialize_params()
+live2 = w2.state_dict()
+assert all(torch.equal(live[k], live2[k].cpu()) for k in live)
 if rank == 0:
     torch.save({"log": out, "master": {k: v.cpu() for k, v in sd.items()}, "live": live}, os.environ["BL_OUT"])
 dist.barrier()
@@ -107,9 +121,10 @@ torch.cuda.set_device(dev)
 dist.init_process_group("nccl", device_id=dev)               # RCCL, one rank
 dims = tiny_dims()
 out = {}
-for mode in ("plain", "rccl-fp32", "rccl-bf16"):
+for mode in ("plain", "rccl-fp32", "rccl-bf16", "rccl-fullshard-fp32", "rccl-fullshard-bf16"):
     w = allocate(dims, dev).fill_synthetic(seed=3)
-    kw = {} if mode == "plain" else dict(force_comm=True, reduce_dtype=torch.bfloat16 if mode.endswith("bf16") else torch.float32)
+    kw = {} if mode == "plain" else dict(force_comm=True, reduce_dtype=torch.bfloat16 if mode.endswith("bf16") else torch.float32,
+                                         shard_params="fullshard" in mode)
     ts = TrainStep(w, "vla-full-train", 2, 20, max_grad_norm=1.0, weight_decay=0.1, **kw)
     log = []
     for step in range(2):
@@ -119,6 +134,9 @@ for mode in ("plain", "rccl-fp32", "rccl-bf16"):
         log.append((loss.item(), norm.item()))
     out[mode] = (log, ts.store.full_master(ts.comm).cpu())
 assert out["plain"][0] == out["rccl-fp32"][0] and torch.equal(out["plain"][1], out["rccl-fp32"][1]), (out["plain"][0], out["rccl-fp32"][0])
+# FULL_SHARD (per-layer all_gather_into_tensor on RCCL, slots, packing on the comm stream) = replicated weights, bit for bit
+assert out["rccl-fullshard-fp32"][0] == out["rccl-fp32"][0] and torch.equal(out["rccl-fullshard-fp32"][1], out["rccl-fp32"][1])
+assert out["rccl-fullshard-bf16"][0] == out["rccl-bf16"][0] and torch.equal(out["rccl-fullshard-bf16"][1], out["rccl-bf16"][1])
 l0, l1 = out["plain"][0], out["rccl-bf16"][0]
 assert all(abs(a[1] - b[1]) <= 2e-2 * a[1] for a, b in zip(l0, l1)), (l0, l1)       # gradients crossed the wire as bf16
 print("RCCL_OK", l0, l1, flush=True)

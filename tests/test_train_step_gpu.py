@@ -164,6 +164,44 @@ def test_recompute_equals_saved_activations(dev, stage):
     assert out[False][2] == dims.llm_layers and out[True][2] == 1 and out[True][3] == dims.llm_layers + 1
 
 
+@pytest.mark.parametrize("stage,recompute", [("vla-full-train", False), ("vla-train", True)])
+def test_parameter_sharding_equals_replicated_weights(dev, stage, recompute):
+    """FSDP FULL_SHARD for the decoder layers (fsdp.py:84-87): the layers' weights leave the model's allocation, each
+    layer is gathered into one of two slots ahead of its forward and its backward, AdamW updates the rank's slice. Same
+    kernels on the same values → bit-identical losses, norms and masters; `materialize_params()` returns the model."""
+    from bridgelang_amd.training.step import TrainStep
+    from bridgelang_amd.weights import allocate, tiny_dims
+    dims = tiny_dims()
+    out = {}
+    for sp in (False, True):
+        w = allocate(dims, dev).fill_synthetic(seed=5)
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_allocated()
+        ts = TrainStep(w, stage, 2, 18, max_grad_norm=1.0, weight_decay=0.1, shard_params=sp, recompute=recompute)
+        assert w.layers_resident == (not sp)
+        log = []
+        for step in range(3):
+            ids, mask, labels, pv = make_batch(dims, 2, 18, seed=30 + step)
+            ts.set_batch(ids, mask, pv, labels)
+            loss, norm = ts.step(1e-3, graph=(step == 2))
+            log.append((loss.item(), norm.item()))
+        if sp:
+            assert all(w.layers[l].qkv_w.data_ptr() == ts._slots[l % 2]["qkv_w"].data_ptr() for l in range(dims.llm_layers))
+            ts.materialize_params()
+            assert w.layers_resident
+            with pytest.raises(RuntimeError):
+                ts.forward()
+        live = {k: v.float().cpu() for k, v in w.state_dict().items()}
+        out[sp] = (log, ts.store.full_master().cpu(), live, {n: ts.store.named_master(n).to(torch.bfloat16).float().cpu()
+                                                            for n in ts.store.by_name})
+    assert out[False][0] == out[True][0]
+    assert torch.equal(out[False][1], out[True][1])
+    for k, v in out[False][2].items():
+        assert torch.equal(v, out[True][2][k]), k
+    for n, v in out[True][3].items():                   # the materialised live weights are the rounded masters
+        assert torch.equal(out[True][2][n], v), n
+
+
 def test_recompute_rejected_with_adapters(dev):
     from bridgelang_amd.training.lora import LoraAdapters
     from bridgelang_amd.training.step import TrainStep
