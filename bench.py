@@ -249,7 +249,7 @@ def train_main(args, rank: int, world: int, dev, distributed: bool) -> None:
     ts = TrainStep(w, args.stage, B, L, max_grad_norm=1.0 if lora is None else float("inf"),
                    weight_decay=0.0 if lora is None else 0.01, lora=lora, world=world, rank=rank,
                    reduce_dtype=torch.float32 if args.reduce == "fp32" else torch.bfloat16, recompute=args.recompute,
-                   shard_params=args.shard_params)
+                   shard_params=args.shard_params, fp8=args.fp8)
     g = torch.Generator().manual_seed(100 + rank)         # each rank draws its own stream (base_strategy.py:259-266)
     ids = torch.randint(3, 31000, (B, L), generator=g)
     ids[:, 0] = 1
@@ -319,7 +319,7 @@ def train_main(args, rank: int, world: int, dev, distributed: bool) -> None:
                        "batch_per_gpu": B, "global_batch": B * world, "seq_len": ts.S, "stage": args.stage,
                        "parallelism": (f"dp{world} sharded-optimizer ({'full-shard: decoder-layer parameters sharded' if args.shard_params else 'shard-grad-op'})"
                                        if world > 1 else "single GPU"),
-                       "hip_graph": graph, "recompute_activations": bool(args.recompute), "shard_params": bool(args.shard_params)},
+                       "hip_graph": graph, "recompute_activations": bool(args.recompute), "shard_params": bool(args.shard_params), "fp8_fwd_dgrad": bool(args.fp8)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "kernel": "tiled MFMA GEMM family (forward, dgrad, wgrad) per bl_gemm_bf16 call",

@@ -257,17 +257,25 @@ class TrainStep:
     def __init__(self, weights: VLAWeights, stage: str, batch: int, prompt_len: int, *, max_grad_norm: float = 1.0,
                  weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8, store: Optional[ParamStore] = None,
                  world: int = 1, rank: int = 0, group=None, reduce_dtype: torch.dtype = torch.float32, lora=None,
-                 force_comm: bool = False, recompute: bool = False, shard_params: bool = False):
+                 force_comm: bool = False, recompute: bool = False, shard_params: bool = False, fp8: bool = False):
         """`lora`: a training.lora.LoraAdapters → stage "lora": the base model is frozen and only the adapters train.
         `recompute`: keep only each decoder layer's input and replay its forward inside the backward pass.
         `shard_params`: FSDP FULL_SHARD for the decoder layers (fsdp.py:84-87) — every rank keeps 1/world of each layer's
         bf16 weights; a layer is all-gathered into one of two slots (and packed into the forward / dgrad layouts there) one
         layer ahead of its forward and again ahead of its backward, on the communication stream; AdamW updates the
-        rank's slice in place. The model's own decoder-layer allocation is freed (`materialize_params()` brings it back)."""
+        rank's slice in place. The model's own decoder-layer allocation is freed (`materialize_params()` brings it back).
+        `fp8`: the decoder layers' forward and input-gradient GEMMs (q/k/v, o, gate/up, down: 2/3 of the step's GEMM work)
+        run W8A8 on the e4m3 MFMA path (BASELINE configs[4]) — activations / output gradients quantised per token row,
+        weights per output channel (forward) and per input channel (the transposed dgrad copy), fp32 accumulation, bf16
+        results; weight gradients stay bf16 x bf16 (TN GEMM), masters and AdamW fp32. No reference counterpart: agreement
+        with the bf16 step is to quantisation noise (tests/test_train_step_gpu.py states the bound)."""
         if (lora is not None) != (stage == "lora"):
             raise ValueError("stage 'lora' and the `lora` adapters go together")
-        if (recompute or shard_params) and lora is not None:
-            raise ValueError("activation recomputation / parameter sharding are planned for the full-parameter stages only")
+        if (recompute or shard_params or fp8) and lora is not None:
+            raise ValueError("activation recomputation / parameter sharding / fp8 GEMMs are planned for the full-parameter stages only")
+        if fp8 and (weights.dims.llm_dim % 128 or weights.dims.llm_inter % 128):
+            raise ValueError("fp8 GEMMs need llm_dim and llm_inter to be multiples of 128")
+        self.fp8 = fp8
         self.recompute, self.shard_params = recompute, shard_params
         self.lora = lora
         self.train_vision = STAGES[stage][0] or lora is not None      # towers need their training-form forward
@@ -289,6 +297,7 @@ class TrainStep:
         dev = weights.embed.device
         self.device = dev
         self._wT: Dict[int, torch.Tensor] = {}       # transposed packed weights for dgrad
+        self._w8: Dict[int, dict] = {}              # packed bf16 weight (data_ptr) → its e4m3 forward / dgrad copies + scales
         self._cur_layer = -1                   # decoder layer whose ops are being planned (slot tensors are shared by layers)
         self._materialized = False
         if shard_params:                       # first: the model's layer allocation is given back before anything else is reserved
@@ -372,6 +381,8 @@ class TrainStep:
         self.vis = [self._alloc_tower(tw) for tw in towers]
         # ---- transposed weights for dgrad ----
         self.ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+        if fp8:
+            self._setup_fp8()
         if lora is not None:
             self._build_extended_weights()
         self.vision_forward_ops: List[Op] = []
@@ -388,6 +399,52 @@ class TrainStep:
                             and reduce_dtype != torch.float32 else None)        # bf16 wire copy of one layer's gradients
 
     # ---- helpers ------------------------------------------------------------------------------------------------
+    # ---- fp8 (e4m3) forward / dgrad GEMMs of the decoder layers ------------------------------------------------------
+    def _setup_fp8(self) -> None:
+        d, dev, Tn = self.dims, self.device, self.T
+        D, I = d.llm_dim, d.llm_inter
+        u8 = lambda *shape: torch.zeros(*shape, dtype=torch.uint8, device=dev)
+        self._q8 = {D: u8(Tn, D), I: u8(Tn, I)}                          # quantised GEMM inputs (one linear at a time)
+        self._q8_dy = u8(Tn, max(3 * D, 2 * I))                          # quantised output gradients
+        self._sx, self._sdy = (torch.zeros(Tn, dtype=torch.float32, device=dev) for _ in range(2))
+        self._fp8_scratch()
+        if self.shard_params:                  # sharded layers are quantised in their gather (slots carry the e4m3 copies)
+            return
+        for lw in self.w.layers:
+            for key in self._LAYER_KEYS:
+                p = getattr(lw, key)
+                n, k = p.shape[0] * 16, p.shape[1] * 32
+                self._w8[p.data_ptr()] = e = self._fp8_entry(n, k, dev)
+                rm = ops.unpack_weight(p).contiguous()                   # start-up only; later the optimizer's bf16 copy
+                ops.run_all(self._fp8_weight_ops(rm, e))
+                del rm
+
+    def _fp8_scratch(self) -> None:
+        if not hasattr(self, "_q_tmp"):
+            D, I = self.dims.llm_dim, self.dims.llm_inter
+            nmax = max(3 * D * D, 2 * I * D)
+            self._q_tmp = torch.zeros(nmax, dtype=torch.uint8, device=self.device)
+            self._t_tmp = torch.zeros(nmax, dtype=torch.bfloat16, device=self.device)
+
+    @staticmethod
+    def _fp8_entry(n: int, k: int, dev) -> dict:
+        return dict(w8=torch.zeros(n // 16, k // 64, 64, 8, dtype=torch.bfloat16, device=dev),
+                    sw=torch.zeros(n, dtype=torch.float32, device=dev),
+                    wT8=torch.zeros(k // 16, n // 64, 64, 8, dtype=torch.bfloat16, device=dev),
+                    swT=torch.zeros(k, dtype=torch.float32, device=dev))
+
+    def _fp8_weight_ops(self, rm: torch.Tensor, e: dict) -> List[Op]:
+        """Logical bf16 weight [n, k] → e4m3 forward copy (scale per output channel n) and e4m3 transposed copy for dgrad
+        (scale per input channel k), both in the fragment-major packing bl_gemm_fp8 reads."""
+        n, k = rm.shape
+        q = self._q_tmp[:n * k].view(n, k)
+        qT = self._q_tmp[:n * k].view(k, n)
+        t = self._t_tmp[:n * k].view(k, n)
+        as_pairs = lambda c: c.view(torch.bfloat16)                    # e4m3 codes as 2-byte units: [r, c] → [r, c / 2]
+        return [ops.quantize_rows_fp8(rm, q, e["sw"], run=False)[2], T.pack(as_pairs(q), e["w8"], run=False),
+                T.transpose_pad(rm, t, n, run=False), ops.quantize_rows_fp8(t, qT, e["swT"], run=False)[2],
+                T.pack(as_pairs(qT), e["wT8"], run=False)]
+
     # ---- parameter sharding (FSDP FULL_SHARD for the decoder layers) ---------------------------------------------------
     _LAYER_KEYS = ("qkv_w", "o_w", "gu_w", "down_w")
 
@@ -409,13 +466,21 @@ class TrainStep:
             for key in self._LAYER_KEYS:
                 p = getattr(L0, key)
                 slot[key] = torch.zeros(tuple(p.shape), dtype=torch.bfloat16, device=dev)
-                slot[key + "T"] = torch.zeros(p.shape[1] * 2, p.shape[0] // 2, 64, 8, dtype=torch.bfloat16, device=dev)
+                if not self.fp8:
+                    slot[key + "T"] = torch.zeros(p.shape[1] * 2, p.shape[0] // 2, 64, 8, dtype=torch.bfloat16, device=dev)
             slot["ready"], slot["free"] = torch.cuda.Event(), torch.cuda.Event()
             self._slots.append(slot)
         self._slot_key = {slot[k].data_ptr(): k for slot in self._slots for k in self._LAYER_KEYS}
+        if self.fp8:
+            self._fp8_scratch()
+            for slot in self._slots:
+                for k in self._LAYER_KEYS:
+                    p = slot[k]
+                    self._w8[p.data_ptr()] = self._fp8_entry(p.shape[0] * 16, p.shape[1] * 32, dev)
         for slot in self._slots:
             for k in self._LAYER_KEYS:
-                self._wT[slot[k].data_ptr()] = slot[k + "T"]
+                if k + "T" in slot:
+                    self._wT[slot[k].data_ptr()] = slot[k + "T"]
         if len(self._sharded_layers) != self.dims.llm_layers:
             raise ValueError("parameter sharding needs every decoder layer trainable (vla-full-train / vla-train)")
         if w.layers_resident:
@@ -431,6 +496,11 @@ class TrainStep:
             for key in self._LAYER_KEYS:
                 u = self._layer_units[(l, key)]
                 rm = slot["flat"][u.offset - b.offset:u.offset - b.offset + u.numel].view(u.group.n, u.group.k)
+                if self.fp8:                   # the slot carries the e4m3 copies (+ scales) instead of the bf16 layouts
+                    q = self._fp8_weight_ops(rm, self._w8[slot[key].data_ptr()])
+                    fwd += q[:2]
+                    bwd += q[2:]
+                    continue
                 fwd.append(T.pack(rm, slot[key], run=False))                              # forward operand layout
                 bwd.append(T.transpose_pack(rm, slot[key + "T"], u.group.n, run=False))   # dgrad operand layout
             self._pack_ops[l] = (fwd, bwd + fwd if self.recompute else bwd)
@@ -548,6 +618,11 @@ class TrainStep:
         """Forward of one nn.Linear. With an adapter: t = x·Aᵀ into the spare columns of x's buffer, then ONE GEMM
         y = [x | t]·[W | s·B]ᵀ over K + R."""
         ad = self.lora.get(packed) if self.lora is not None else None
+        e8 = self._w8.get(packed.data_ptr())
+        if e8 is not None:                                 # decoder-layer linear on the e4m3 MFMA path
+            q = self._q8[x.shape[1]]
+            return [ops.quantize_rows_fp8(x, q, self._sx, run=False)[2],
+                    ops.gemm_fp8(q, self._sx, e8["w8"], e8["sw"], out, epilogue, run=False, **kw)]
         if ad is None:
             return [self._g(x, packed, out, epilogue, **kw)]
         K, R = x.shape[1], ad.R
@@ -564,7 +639,12 @@ class TrainStep:
         ad = self.lora.get(packed) if self.lora is not None else None
         if ad is None:
             plan = self._wgrad(dy, x, packed)
-            if dx is not None:
+            e8 = self._w8.get(packed.data_ptr())
+            if dx is not None and e8 is not None:          # dx = dy · W on the e4m3 path (dy per token row, Wᵀ per input channel)
+                q = self._q8_dy[:, :dy.shape[1]]
+                plan += [ops.quantize_rows_fp8(dy, q, self._sdy, run=False)[2],
+                         ops.gemm_fp8(q, self._sdy, e8["wT8"], e8["swT"], dx, EPI_NONE, run=False)]
+            elif dx is not None:
                 plan.append(self._dgrad(dy, packed, dx))
             return plan
         i, st, s, R, N = ad.index, self.store, self.lora.scaling, ad.R, dy.shape[1]
@@ -853,6 +933,8 @@ class TrainStep:
             key = u.group.packed.data_ptr()
             if key in self._wT:                                   # only weights that a dgrad GEMM actually reads
                 plan.append(T.transpose_pack(rm, self._wT[key], n, run=False))
+            if key in self._w8:                                   # e4m3 copies follow the updated weight
+                plan += self._fp8_weight_ops(rm, self._w8[key])
         plan += self._adapter_ops                                 # LoRA: adapter columns of the K-concatenated weights
         return plan
 
