@@ -12,7 +12,9 @@ of where this runs: (i) nothing is downloaded — `--vla.base_vlm` must be a loc
 `--pretrained_checkpoint` is given, and `--synthetic_init True` builds the named architecture with the seeded synthetic
 checkpoint (benchmark / smoke runs); (ii) the RLDS/TFDS reader is outside the hot path: `--vla.data_mix
 dummy` trains on `DummyDataset` (vla/datasets.py), any other mixture needs an RLDS reader and raises; (iii) trackers: `jsonl`
-(W&B is a network service); (iv) `--tokenizer synthetic|<dir>` names the tokenizer (none ships offline).
+(W&B is a network service); (iv) `--tokenizer synthetic|<dir>` names the tokenizer (none ships offline); (v) `--fp8_gemms True`
+runs the decoder layers' forward / input-gradient GEMMs on the e4m3 MFMA path (an extension; BASELINE configs[4]).
+`--vla.train_strategy fsdp-full-shard` shards the decoder layers' parameters, `fsdp-shard-grad-op` keeps them replicated.
 One process per GPU under torchrun (RANK / LOCAL_RANK / WORLD_SIZE); collectives are RCCL over xGMI.
 """
 from __future__ import annotations
@@ -55,6 +57,7 @@ class TrainConfig:
     synthetic_init: bool = False
     tokenizer: str = "synthetic"
     dummy_length: int = 10000
+    fp8_gemms: bool = False                        # decoder-layer forward / dgrad GEMMs on the e4m3 MFMA path (BASELINE configs[4])
     # fmt: on
 
     def __post_init__(self) -> None:
@@ -151,7 +154,7 @@ def train(cfg: TrainConfig) -> Path:
         weight_decay=cfg.weight_decay, max_grad_norm=cfg.max_grad_norm, lr_scheduler_type=cfg.lr_scheduler_type,
         warmup_ratio=cfg.warmup_ratio, enable_gradient_checkpointing=cfg.vla.enable_gradient_checkpointing,
         enable_mixed_precision_training=cfg.vla.enable_mixed_precision_training,
-        reduce_in_full_precision=cfg.vla.reduce_in_full_precision)
+        reduce_in_full_precision=cfg.vla.reduce_in_full_precision, fp8_gemms=cfg.fp8_gemms)
     strategy.run_setup(run_dir=run_dir, n_train_examples=len(vla_dataset))
     metrics = VLAMetrics(tuple(t for t in cfg.trackers if t != "wandb"), cfg.run_id, run_dir, cli.encode(cfg),
                          resume_step=cfg.resume_step, resume_epoch=cfg.resume_epoch)
