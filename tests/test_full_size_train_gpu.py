@@ -113,3 +113,44 @@ def test_full_finetune_wgrad_consistent_with_lora_full_size(dev):
         assert c > 0.995 and rel < 0.1, (n, c, rel)
     del tl, lora, w
     torch.cuda.empty_cache()
+
+
+def test_cfg5_form_at_13b_widths(dev):
+    """BASELINE configs[4]'s combination at the 13B layer widths (hidden 5120, 40 heads, inter 13824; four decoder layers so
+    the optimizer state stays at 40 GB): full-shard parameter gathers + e4m3 forward / dgrad GEMMs + activation recomputation
+    must reproduce the replicated-weight fp8 step bit for bit, step after step (the whole 40-layer model in this form is
+    timed by `bench.py --mode train --model prism-13b --shard-params --fp8 --recompute`, profiles/)."""
+    import dataclasses
+    from bridgelang_amd.training.step import TrainStep
+    from bridgelang_amd.weights import allocate, prism_13b_dims
+    dims = dataclasses.replace(prism_13b_dims(), llm_layers=4)
+    B, L = 4, 32
+    g = torch.Generator().manual_seed(1)
+    batches = []
+    for _ in range(2):
+        ids = torch.randint(3, 31000, (B, L), generator=g)
+        ids[:, 0] = 1
+        ids[:, -8:-1] = torch.randint(31744, 32000, (B, 7), generator=g)
+        ids[:, -1] = 2
+        labels = torch.full((B, L), -100)
+        labels[:, -8:] = ids[:, -8:]
+        batches.append((ids, labels, torch.randn(B, 6, 224, 224, generator=g).to(torch.bfloat16)))
+    out = {}
+    for sharded in (False, True):
+        w = allocate(dims, dev).fill_synthetic(seed=0)
+        ts = TrainStep(w, "vla-train", B, L, max_grad_norm=1.0, weight_decay=0.1, fp8=True, shard_params=sharded,
+                       recompute=sharded)
+        log = []
+        for ids, labels, pv in batches:
+            ts.set_batch(ids, None, pv, labels)
+            loss, norm = ts.step(1e-4)
+            log.append((loss.item(), norm.item()))
+        out[sharded] = (log, ts.store.full_master().cpu())
+        assert w.layers_resident == (not sharded)
+        del ts, w
+        gc.collect()
+        torch.cuda.empty_cache()
+    print(out[False][0], out[True][0])
+    assert all(l == l and n == n and n > 0 for l, n in out[True][0])                 # finite
+    assert out[False][0] == out[True][0]
+    assert torch.equal(out[False][1], out[True][1])
