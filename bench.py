@@ -446,7 +446,7 @@ def main() -> None:
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_note": "avg HBM+Infinity-Cache bytes per bl_gemm_bf16 call over the 4 Llama prefill GEMMs, separate --pmc passes (profiles/pmc_r02_final/gemm_traffic.json)",
                          "kernel": ("gemm256s_fp8_kernel (per bl_gemm_fp8 call)" if args.fp8 else
-                                    "tiled MFMA GEMM family: gemm256s_kernel / gemm288_kernel + gemm_tail_kernel (per bl_gemm_bf16 call)"), "launches_per_step": gemm["launches"],
+                                    "tiled MFMA GEMM family: gemm256s_kernel / gemm288s_kernel + gemm_tail_kernel (per bl_gemm_bf16 call)"), "launches_per_step": gemm["launches"],
                          "avg_launch_us": round(gemm["ms"] * 1e3 / gemm["launches"], 2),
                          "algorithmic_gflop_per_launch": round(gemm["flops"] / gemm["launches"] / 1e9, 3)},
             "end_to_end": {"algorithmic_tflop_per_seq": round(algo, 3),
