@@ -60,6 +60,9 @@ class OpenVLAEngine:
         holds the decoder-layer weights (parameter-sharded training frees them)."""
         self.w, self.dims = weights, weights.dims
         self.vision_only = vision_only
+        if not vision_only and not weights.layers_resident:
+            raise RuntimeError("the decoder-layer weights are sharded out of the model (parameter-sharded training in progress): "
+                               "call the strategy's finish() / TrainStep.materialize_params() before building an inference engine")
         self.padded = padded
         use_mask = use_mask or padded
         if padded and (all_rows or fp8):

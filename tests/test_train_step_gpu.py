@@ -187,6 +187,9 @@ def test_parameter_sharding_equals_replicated_weights(dev, stage, recompute):
             log.append((loss.item(), norm.item()))
         if sp:
             assert all(w.layers[l].qkv_w.data_ptr() == ts._slots[l % 2]["qkv_w"].data_ptr() for l in range(dims.llm_layers))
+            from bridgelang_amd.engine import OpenVLAEngine
+            with pytest.raises(RuntimeError):               # no inference over a model whose layers are sharded out
+                OpenVLAEngine(w, 2, 18)
             ts.materialize_params()
             assert w.layers_resident
             with pytest.raises(RuntimeError):
