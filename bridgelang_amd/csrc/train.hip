@@ -558,26 +558,29 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const uint16_t* P, l
   for (int i = 0; i < RB; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   auto pswz = [](int row) { return (PROW == 256) ? tr_swz8(row) : tr_swz(row); };
-  u32x4_t qreg, preg[PLD];
-  auto load = [&](int t0) {
+  // Register ring of D steps: the rows of step s + D are requested while step s is multiplied, so D − 1 steps (8 KiB each at
+  // R = 64) are in flight per workgroup — with one step ahead the kernel moved 0.8 TB/s (one load latency per 32 rows).
+  constexpr int D = 6;
+  u32x4_t qreg[D], preg[D][PLD];
+  auto load = [&](int slot, int t0) {
     const int row = tid >> 3, ch = tid & 7;
-    qreg = (u32x4_t){0u, 0u, 0u, 0u};
-    if (t0 + row < t_end) qreg = *(const u32x4_t*)(Q + (long)(t0 + row) * ldq + n0 + ch * 8);
+    qreg[slot] = (u32x4_t){0u, 0u, 0u, 0u};
+    if (t0 + row < t_end) qreg[slot] = *(const u32x4_t*)(Q + (long)(t0 + row) * ldq + n0 + ch * 8);
 #pragma unroll
     for (int u = 0; u < PLD; ++u) {
       const int piece = tid + 256 * u, prow = piece / PCH, pch = piece - prow * PCH;
-      preg[u] = (u32x4_t){0u, 0u, 0u, 0u};
-      if (piece < 32 * PCH && t0 + prow < t_end) preg[u] = *(const u32x4_t*)(P + (long)(t0 + prow) * ldp + pch * 8);
+      preg[slot][u] = (u32x4_t){0u, 0u, 0u, 0u};
+      if (piece < 32 * PCH && t0 + prow < t_end) preg[slot][u] = *(const u32x4_t*)(P + (long)(t0 + prow) * ldp + pch * 8);
     }
   };
-  auto stage = [&](int buf) {
+  auto stage = [&](int slot, int buf) {
     const int row = tid >> 3, ch = tid & 7;
-    *(u32x4_t*)(q_lds[buf] + row * 128 + (((((ch >> 1) ^ tr_swz(row)) << 1) | (ch & 1)) << 4)) = qreg;
+    *(u32x4_t*)(q_lds[buf] + row * 128 + (((((ch >> 1) ^ tr_swz(row)) << 1) | (ch & 1)) << 4)) = qreg[slot];
 #pragma unroll
     for (int u = 0; u < PLD; ++u) {
       const int piece = tid + 256 * u, prow = piece / PCH, pch = piece - prow * PCH;
       if (piece < 32 * PCH)
-        *(u32x4_t*)(p_lds[buf] + prow * PROW + (((((pch >> 1) ^ pswz(prow)) << 1) | (pch & 1)) << 4)) = preg[u];
+        *(u32x4_t*)(p_lds[buf] + prow * PROW + (((((pch >> 1) ^ pswz(prow)) << 1) | (pch & 1)) << 4)) = preg[slot][u];
     }
   };
   // transposing fragment: 8 consecutive rows (8·lg + j) of column block `cb` (16 columns) of a staged tile
@@ -594,25 +597,30 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const uint16_t* P, l
     return __builtin_bit_cast(bf16x8_t, o);
   };
 
-  int buf = 0;
-  if (t_begin < t_end) {
-    load(t_begin);
-    stage(0);
-  }
-  __syncthreads();
-  for (int t0 = t_begin; t0 < t_end; t0 += 32) {
-    const bool more = t0 + 32 < t_end;
-    if (more) load(t0 + 32);                                   // global loads of the next step fly under this step's MFMAs
-    const bf16x8_t qf = frag(q_lds[buf], 128, wave, false);
+  const int nsteps = t_begin < t_end ? (t_end - t_begin + 31) / 32 : 0;
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-      const bf16x8_t pf = frag(p_lds[buf], PROW, rb, true);
-      acc[rb] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf, acc[rb], 0, 0, 0)
-                      : __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, pf, acc[rb], 0, 0, 0);
+  for (int d = 0; d < D; ++d) load(d, t_begin + 32 * d);         // rows past t_end come back as zeros
+  if (nsteps) stage(0, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int base = 0; base < nsteps; base += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      const int st = base + u;
+      if (st < nsteps) {                                           // uniform
+        load(u, t_begin + 32 * (st + D));                          // slot u (step st, staged one step ago) ← step st + D
+        const bf16x8_t qf = frag(q_lds[buf], 128, wave, false);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          const bf16x8_t pf = frag(p_lds[buf], PROW, rb, true);
+          acc[rb] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf, acc[rb], 0, 0, 0)
+                          : __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, pf, acc[rb], 0, 0, 0);
+        }
+        if (st + 1 < nsteps) stage((u + 1) % D, buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+      }
     }
-    if (more) stage(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
   }
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
@@ -994,6 +1002,7 @@ extern "C" int bl_gemm_tn_small_bf16(const bl_bf16* P, int64_t ldp, const bl_bf1
   if (!bl_aligned16(P) || !bl_aligned16(Q) || !bl_aligned16(C)) return BL_E_ALIGN;
   if (ldc != (transpose_out ? R : N)) return BL_E_SHAPE;          // dense output (the split partials mirror it)
   // split T until the grid has ≥ 256 workgroups, when the caller provides room for the partials
+  // (≥ 1024 was measured too: no faster, and every split call pays a reduce launch)
   const int slabs = N / 64;
   int splits = 1;
   while (slabs * splits < 256 && (T + splits * 2 - 1) / (splits * 2) >= 256 && partial_ws &&
