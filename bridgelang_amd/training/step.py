@@ -923,7 +923,12 @@ class TrainStep:
         st = self.store
         nmax = max((u.numel for u in st.units), default=8)
         self._tW = torch.zeros(nmax, dtype=torch.bfloat16, device=self.device)
-        self._plain_copies = [(u.dst, st.stage_view(u.offset, u.numel)) for u in st.units if u.group is None]
+        # plain tensors (norm scales, biases, embeddings, LoRA adapters): updated bf16 values → the live tensors, as prepared
+        # byte copies inside the plan (hundreds of them under LoRA: replayed with the graph instead of launched one by one)
+        for u in st.units:
+            if u.group is None:
+                assert u.dst.is_contiguous()
+                plan.append(T.copy_f32(st.stage_view(u.offset, u.numel), u.dst, run=False))
         for u in st.units:
             if u.group is None or st.layout.buckets[u.bucket].key in st.sharded_keys:
                 continue                                          # parameter-sharded layers are packed when gathered
@@ -1072,8 +1077,6 @@ class TrainStep:
                     self.comm.all_gather_params(st.stage_view(b.offset, b.numel), b)
         if self.comm.active:
             main.wait_stream(self._comm_stream)
-        for dst, src in self._plain_copies:
-            dst.copy_(src)
         self._replay("repack", self.repack_ops, graph)
 
     def step(self, lr: float, graph: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
