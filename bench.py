@@ -448,7 +448,10 @@ def main() -> None:
                          "kernel": ("gemm256s_fp8_kernel (per bl_gemm_fp8 call)" if args.fp8 else
                                     "tiled MFMA GEMM family: gemm256s_kernel / gemm288s_kernel + gemm_tail_kernel (per bl_gemm_bf16 call)"), "launches_per_step": gemm["launches"],
                          "avg_launch_us": round(gemm["ms"] * 1e3 / gemm["launches"], 2),
-                         "algorithmic_gflop_per_launch": round(gemm["flops"] / gemm["launches"] / 1e9, 3)},
+                         "algorithmic_gflop_per_launch": round(gemm["flops"] / gemm["launches"] / 1e9, 3),
+                         "sustained_mfma_note": ("`peak` is the dense bf16 spec figure; a register-only stream of the same MFMA on "
+                                                 "N(0,1) operands sustains 1611 TFLOP/s on this pool (power cap; tools/micro/"
+                                                 "w4_ceiling.hip, DESIGN §3)" if not args.fp8 else None)},
             "end_to_end": {"algorithmic_tflop_per_seq": round(algo, 3),
                            "mfma_util_whole_step": round(value / world * algo / BF16_MFMA_PEAK_TFLOPS, 4),
                            "kernel_ms_per_step_eager_events": round(kern_ms, 3),
