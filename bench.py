@@ -302,7 +302,9 @@ def train_main(args, rank: int, world: int, dev, distributed: bool) -> None:
         for i, op in enumerate(plan):
             a = agg.setdefault(op.name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             a["launches"] += 1; a["ms"] += evs[i].elapsed_time(evs[i + 1]); a["flops"] += op.flops; a["bytes"] += op.bytes
-        gemm = agg["bl_gemm_bf16"]
+        # the tiled MFMA GEMM family: NT (forward, dgrad), TN (wgrad) and, with --fp8, the e4m3 forward / dgrad launches
+        fam = [agg[k] for k in ("bl_gemm_bf16", "bl_gemm_tn_bf16", "bl_gemm_fp8") if k in agg]
+        gemm = {f: sum(a[f] for a in fam) for f in ("ms", "flops", "launches")}
         achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
         model_flops = sum(op.flops for op in plan)
         ms = elapsed / args.steps * 1e3
@@ -322,7 +324,7 @@ def train_main(args, rank: int, world: int, dev, distributed: bool) -> None:
                        "hip_graph": graph, "recompute_activations": bool(args.recompute), "shard_params": bool(args.shard_params), "fp8_fwd_dgrad": bool(args.fp8)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "tiled MFMA GEMM family (forward, dgrad, wgrad) per bl_gemm_bf16 call",
+                         "kernel": "tiled MFMA GEMM family per call: bl_gemm_bf16 (forward, dgrad), bl_gemm_tn_bf16 (wgrad)" + (", bl_gemm_fp8 (e4m3 forward / dgrad; priced against the bf16 peak)" if args.fp8 else ""),
                          "launches_per_step": gemm["launches"], "avg_launch_us": round(gemm["ms"] * 1e3 / gemm["launches"], 2),
                          "algorithmic_gflop_per_launch": round(gemm["flops"] / gemm["launches"] / 1e9, 3)},
             "end_to_end": {"model_tflop_per_step_per_gpu": round(model_flops / 1e12, 2),
