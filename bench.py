@@ -66,6 +66,11 @@ def parse() -> argparse.Namespace:
                     help="--mode train: FSDP FULL_SHARD for the decoder layers (parameters sharded over the ranks, gathered per layer)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / fence / JSON plumbing only (gloo, no GPU, a sleep per step): the CPU test of --gpus N")
+    ap.add_argument("--train-legs", default="auto", choices=["auto", "on", "off"],
+                    help="--mode infer: after the inference measurement (engines freed) also time 3 steps each of BASELINE "
+                         "configs[2]'s per-GPU shape (vla-full-train, B = 32) and configs[3] (LoRA r = 32, B = 16) and report them "
+                         "under end_to_end.train_cfg2_n1 / train_cfg3_lora_n1 of the same JSON line; auto = the default 1-GPU "
+                         "openvla-7b run only")
     ap.add_argument("--pipeline", type=int, default=7, choices=[1, 2, 7, 8],
                     help="2 = overlap batch i's decode with batch i+1's vision+prefill (TwoStagePipeline); 7 = StaggeredDecodePipeline "
                          "(one merged decode iteration over the 6 older batches per step)")
@@ -234,9 +239,19 @@ def dry_run(args, rank: int, world: int) -> None:
 
 
 def train_main(args, rank: int, world: int, dev, distributed: bool) -> None:
+    line = train_line(args, rank, world, dev)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if distributed:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def train_line(args, rank: int, world: int, dev) -> dict:
     """BASELINE configs[2] (full fine-tune, per-GPU batch 32, S = 296, sharded optimizer over the ranks) / configs[3]
     (LoRA r = 32, batch 16): one `run_vla_training` iteration per step — forward, backward (bucket reduce-scatter
-    overlapped), global-norm clip, AdamW, weight re-pack / all-gather (base_strategy.py:284-366, fsdp.py:135-270)."""
+    overlapped), global-norm clip, AdamW, weight re-pack / all-gather (base_strategy.py:284-366, fsdp.py:135-270).
+    Returns the JSON record (rank 0; None elsewhere)."""
     from bridgelang_amd import replicas, weights as W
     from bridgelang_amd.training.step import TrainStep
     dims = {"openvla-7b": W.openvla_7b_dims, "prism-13b": W.prism_13b_dims, "openvla-tiny": W.tiny_dims}[args.model]()
@@ -337,10 +352,40 @@ def train_main(args, rank: int, world: int, dev, distributed: bool) -> None:
                            "hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                            "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)]},
         }
-        print(json.dumps(line), flush=True)
-    if distributed:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+        return line
+    return None
+
+
+def train_legs(args, dev) -> dict:
+    """BASELINE configs[2] / configs[3] on the same clock as the headline: after the inference engines are freed, 1 warm-up
+    + 3 timed steps each of the full fine-tune at its per-GPU shape (B = 32, S = 296; base_strategy.py:284-366) and of the
+    LoRA r = 32 step (B = 16; vla-scripts/finetune.py:253-318), through the same train_line() `--mode train` prints. A leg
+    that fails (e.g. out of memory on a box with less free HBM) is reported as {"error": …}; it never costs the headline."""
+    import copy
+    import gc
+    out = {}
+    for key, stage, batch in (("train_cfg2_n1", "vla-full-train", 32), ("train_cfg3_lora_n1", "lora", 16)):
+        a = copy.copy(args)
+        a.mode, a.stage, a.batch, a.steps, a.warmup = "train", stage, batch, 3, 1
+        a.recompute = a.shard_params = a.fp8 = False
+        a.reduce = "fp32"
+        gc.collect()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        t0 = time.perf_counter()
+        try:
+            ln = train_line(a, 0, 1, dev)
+            e2e = ln["end_to_end"]
+            out[key] = {"ms_per_step": ln["ms_per_step"], "samples_per_s": ln["value"], "steps": 3, "warmup": 1,
+                        "mfma_util_whole_step": e2e["mfma_util_whole_step"], "model_tflop_per_step": e2e["model_tflop_per_step_per_gpu"],
+                        "gemm_family_tflops_per_call": ln["roofline"]["achieved"], "phases_ms_eager_events": e2e["phases_ms_eager_events"],
+                        "hbm_gib": e2e["hbm_gib"], "loss_first_last": e2e["loss_first_last"], "workload": ln["config"]["workload"],
+                        "leg_wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as exc:                                      # noqa: BLE001 — report, keep the headline
+            out[key] = {"error": f"{type(exc).__name__}: {str(exc)[:300]}", "leg_wall_s": round(time.perf_counter() - t0, 1)}
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
 
 
 def main() -> None:
@@ -470,6 +515,13 @@ def main() -> None:
                                                        "which reproduce the per-batch weight-streaming kernels' fp32 summation order: ids "
                                                        "and logits are bit-identical to the one-batch engine "
                                                        "(tests/test_full_size_gpu.py::test_staggered_pipeline_full_size)")
+        legs = args.train_legs == "on" or (args.train_legs == "auto" and world == 1 and args.model == "openvla-7b"
+                                           and not args.fp8 and args.pipeline == 7 and args.batch == 16)
+        if legs and world == 1:          # training on the same clock: free the inference state first
+            if args.pipeline != 1:
+                del pipe
+            del eng, w, prof
+            line["end_to_end"].update(train_legs(args, dev))
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would wait at the barrier)
             line["cpu_baseline"] = cpu_baseline(dims, args.batch, args.prompt_len)
         print(json.dumps(line), flush=True)

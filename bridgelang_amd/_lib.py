@@ -115,6 +115,7 @@ SIGNATURES = {
     "bl_embed_backward_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "bl_preprocess_u8_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "bl_resample_pass_u8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "bl_crop_resize_bilinear_u8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp]),
     "bl_im2col_patch14_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _vp]),
     "bl_write_prefix_tokens_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp]),
 }

@@ -286,6 +286,46 @@ __global__ void resample_pass_kernel(const uint8_t* src, uint8_t* dst, int B, in
   }
 }
 
+// tf.image.crop_and_resize for uint8 frames, as the robot evaluation loops apply it (`get_vla_action(center_crop=True)`,
+// experiments/robot/openvla_utils.py:81-155: convert_image_dtype(uint8 → float32) → crop_and_resize(bilinear, one centred
+// box) → clip [0, 1] → convert_image_dtype(float32 → uint8, saturate) ), one thread per output pixel (3 channels):
+//   ys = y_base + i · y_step, xs likewise (fp32, the two constants come from the host so both sides use the same bits);
+//   0 outside [0, H-1] × [0, W-1]; else v = (1-wy)·((1-wx)·p00 + wx·p01) + wy·((1-wx)·p10 + wx·p11) on p = u8 · (1/255)
+//   out = (uint8) clamp(clamp(v, 0, 1) · 255.5, 0, 255)       (TF scales by 255.5 and truncates when it saturates).
+// Every fp32 operation is a separate, individually rounded instruction (no FMA contraction), in the order of the host
+// restatement vla/eval_preprocess.py::crop_and_resize_bilinear — results are bit-identical to it.
+__global__ void crop_resize_bilinear_kernel(const uint8_t* src, uint8_t* dst, int B, int H, int W, int oh, int ow,
+                                            float y_base, float y_step, float x_base, float x_step) {
+  const long total = (long)B * oh * ow;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(t % ow), i = (int)((t / ow) % oh);
+    const long b = t / ((long)ow * oh);
+    const float ys = __fadd_rn(y_base, __fmul_rn((float)i, y_step));
+    const float xs = __fadd_rn(x_base, __fmul_rn((float)j, x_step));
+    uint8_t* q = dst + t * 3;
+    if (!(ys >= 0.0f && ys <= (float)(H - 1) && xs >= 0.0f && xs <= (float)(W - 1))) { q[0] = q[1] = q[2] = 0; continue; }
+    const float fy = floorf(ys), fx = floorf(xs);
+    const float wy = __fsub_rn(ys, fy), wx = __fsub_rn(xs, fx);
+    const float wy1 = __fsub_rn(1.0f, wy), wx1 = __fsub_rn(1.0f, wx);
+    const int y0 = min(max((int)fy, 0), H - 1), y1 = min(max((int)fy + 1, 0), H - 1);
+    const int x0 = min(max((int)fx, 0), W - 1), x1 = min(max((int)fx + 1, 0), W - 1);
+    const uint8_t* r0 = src + (b * H + y0) * (long)W * 3;
+    const uint8_t* r1 = src + (b * H + y1) * (long)W * 3;
+    const float k = 1.0f / 255.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float p00 = __fmul_rn((float)r0[x0 * 3 + c], k), p01 = __fmul_rn((float)r0[x1 * 3 + c], k);
+      const float p10 = __fmul_rn((float)r1[x0 * 3 + c], k), p11 = __fmul_rn((float)r1[x1 * 3 + c], k);
+      const float top = __fadd_rn(__fmul_rn(p00, wx1), __fmul_rn(p01, wx));
+      const float bot = __fadd_rn(__fmul_rn(p10, wx1), __fmul_rn(p11, wx));
+      float v = __fadd_rn(__fmul_rn(top, wy1), __fmul_rn(bot, wy));
+      v = fminf(fmaxf(v, 0.0f), 1.0f);
+      v = fminf(fmaxf(__fmul_rn(v, 255.5f), 0.0f), 255.0f);
+      q[c] = (uint8_t)v;
+    }
+  }
+}
+
 inline int grid_for(long total, int block) {
   long g = (total + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));   // cap at 256 CUs × 8 and grid-stride the rest
@@ -403,6 +443,16 @@ extern "C" int bl_resample_pass_u8(const uint8_t* src, uint8_t* dst, int32_t B, 
   else
     hipLaunchKernelGGL(resample_pass_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, B,
                        lines, in_len, out_len, bounds, coefs, ksize);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_crop_resize_bilinear_u8(const uint8_t* src, uint8_t* dst, int32_t B, int32_t H, int32_t W, int32_t out_h,
+                                          int32_t out_w, float y_base, float y_step, float x_base, float x_step, void* stream) {
+  if (!src || !dst) return BL_E_ARG;
+  if (B <= 0 || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0) return BL_E_SHAPE;
+  hipLaunchKernelGGL(crop_resize_bilinear_kernel, dim3(grid_for((long)B * out_h * out_w, 256)), dim3(256), 0, (hipStream_t)stream,
+                     src, dst, B, H, W, out_h, out_w, y_base, y_step, x_base, x_step);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

@@ -42,7 +42,7 @@ def _fp8_layers(weights: VLAWeights) -> list:
 class OpenVLAEngine:
     def __init__(self, weights: VLAWeights, batch: int, prompt_len: int, n_new: int = 7, all_rows: bool = False,
                  use_mask: bool = False, splitk: bool = False, fp8: bool = False, padded: bool = False,
-                 vision_only: bool = False):
+                 vision_only: bool = False, text_only: bool = False):
         """all_rows=True builds the training/eval-style forward instead of generation: logits for every position
         (`logits_all` [B*S, vocab] fp32) and no decode steps. use_mask=True threads a [B, S] uint8 key-padding mask
         (`key_mask`, 1 = attend) through the Llama attention (modeling_prismatic.py:387-390). splitk=True lets
@@ -57,9 +57,13 @@ class OpenVLAEngine:
         comes from ITS last real position, and the new tokens are rotated at the sequence's own position — every
         sequence gets exactly the ids and logits it gets alone, un-padded (tests/test_hf_boundary_gpu.py).
         vision_only=True plans the towers alone (the training step's frozen front end): no Llama plans, so nothing here
-        holds the decoder-layer weights (parameter-sharded training frees them)."""
+        holds the decoder-layer weights (parameter-sharded training frees them). text_only=True plans the reference's
+        language-only forward (`pixel_values is None`, modeling_prismatic.py:343-359): no towers, no projector, S = L."""
         self.w, self.dims = weights, weights.dims
-        self.vision_only = vision_only
+        self.vision_only, self.text_only = vision_only, text_only
+        if text_only and (vision_only or padded or fp8):
+            raise ValueError("text_only is the plain bf16 language-model plan")
+        self.epoch = 0            # bumped by every prefill that overwrites the KV caches (cache handles check it)
         if not vision_only and not weights.layers_resident:
             raise RuntimeError("the decoder-layer weights are sharded out of the model (parameter-sharded training in progress): "
                                "call the strategy's finish() / TrainStep.materialize_params() before building an inference engine")
@@ -72,7 +76,8 @@ class OpenVLAEngine:
             n_new = 1
         self.all_rows, self.use_mask = all_rows, use_mask
         self.B, self.L, self.n_new = batch, prompt_len, n_new
-        self.S = prompt_len + d.n_patches
+        self.n_patches = 0 if text_only else d.n_patches
+        self.S = prompt_len + self.n_patches
         self.cache_len = (self.S + n_new + 63) // 64 * 64
         if self.cache_len > d.max_pos:
             raise ValueError("sequence exceeds max_position_embeddings")
@@ -127,14 +132,14 @@ class OpenVLAEngine:
             self.h8, self.act8 = z(B * S, D, dtype=torch.uint8), z(B * S, I, dtype=torch.uint8)
             self.sq = z(B * S, dtype=torch.float32)
 
-        self.dino_ops = self._plan_tower(weights.dino, 0, self.vbuf[0])
-        self.siglip_ops = self._plan_tower(weights.siglip, d.dino.dim, self.vbuf[1])
+        self.dino_ops = [] if text_only else self._plan_tower(weights.dino, 0, self.vbuf[0])
+        self.siglip_ops = [] if text_only else self._plan_tower(weights.siglip, d.dino.dim, self.vbuf[1])
         self.vision_ops = self.dino_ops + self.siglip_ops      # serial order (profiling / single-stream use)
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         if vision_only:
             self.projector_ops, self.prefill_ops, self.decode_ops = [], [], []
         else:
-            self.projector_ops = self._plan_projector()
+            self.projector_ops = [] if text_only else self._plan_projector()
             self.prefill_ops = self._plan_prefill()
             self.decode_ops = [self._plan_decode(t) for t in range(1, n_new)]
         self._graph: Optional[torch.cuda.CUDAGraph] = None
@@ -199,7 +204,8 @@ class OpenVLAEngine:
         h, qkv, ao, act = self.h[rows], self.qkv[rows], self.ao[rows], self.act[rows]
         xd, hdd, aod, actd = self.xd[b0:b1], self.hd[b0:b1], self.aod[b0:b1], self.actd[b0:b1]
         key_mask = self.key_mask[b0:b1] if self.key_mask is not None else None
-        plan = [ops.embed_splice(self.input_ids[b0:b1], w.embed, x3, d.n_patches, run=False)]
+        plan = [ops.embed_splice(self.input_ids[b0:b1], w.embed, x3, self.n_patches, run=False)]
+        self.layer_ends: List[int] = []       # len(plan) after each decoder layer (hidden-state taps of the all_rows plan)
         cs = (H * self.cache_len * hd, self.cache_len * hd, hd)
         # Generation consumes only the last position of the last layer (the reference materialises all S rows of every
         # layer): that layer still projects K/V for every position (the decode steps attend to them),
@@ -224,6 +230,7 @@ class OpenVLAEngine:
                 plan.append(ops.gemm_fp8(h8, sq, *w8["gu_w"], act, EPI_SWIGLU, run=False))
                 plan.append(q8(act, act8))
                 plan.append(ops.gemm_fp8(act8, sq, *w8["down_w"], x, EPI_RES, res=x, run=False))
+                self.layer_ends.append(len(plan))
                 continue
             if not last and hd == 128 and S <= 320:
                 # RoPE and the KV-cache write ride inside the attention kernel's q / k / v loads
@@ -233,6 +240,7 @@ class OpenVLAEngine:
                 plan.append(ops.rmsnorm(x, lw.ln2, h, d.rms_eps, run=False))
                 plan.append(self._g(h, lw.gu_w, act, EPI_SWIGLU, run=False))
                 plan.append(self._g(act, lw.down_w, x, EPI_RES, res=x, run=False))
+                self.layer_ends.append(len(plan))
                 continue
             plan.append(ops.rope_kvcache(qkv, self.cos, self.sin, kc, vc, B=B, S=S, H=H, head_dim=hd, pos0=0, run=False))
             if last and self.padded:
@@ -268,6 +276,7 @@ class OpenVLAEngine:
             plan.append(ops.rmsnorm(x, lw.ln2, h, d.rms_eps, run=False))
             plan.append(self._g(h, lw.gu_w, act, EPI_SWIGLU, run=False))
             plan.append(self._g(act, lw.down_w, x, EPI_RES, res=x, run=False))
+            self.layer_ends.append(len(plan))
         if self.all_rows:   # HF semantics: logits for every position (what forward()/training consume)
             plan.append(ops.rmsnorm(x, w.norm, h, d.rms_eps, run=False))
             plan.append(self._g(h, w.lm_head, self.logits_all[rows], EPI_F32_BF16R, run=False))
@@ -373,10 +382,17 @@ class OpenVLAEngine:
     def set_inputs(self, input_ids: torch.Tensor, pixel_values: torch.Tensor) -> None:
         if tuple(input_ids.shape) != (self.B, self.L):
             raise ValueError(f"engine built for input_ids {(self.B, self.L)}, got {tuple(input_ids.shape)}")
+        if self.text_only:
+            if pixel_values is not None:
+                raise ValueError("a text_only engine takes no pixel_values")
+            self.input_ids.copy_(input_ids)
+            self.epoch += 1
+            return
         if tuple(pixel_values.shape) != (self.B, 6, 224, 224):
             raise ValueError(f"pixel_values must be [{self.B}, 6, 224, 224]")
         self.input_ids.copy_(input_ids)
         self.pixel_values.copy_(pixel_values.to(torch.bfloat16))
+        self.epoch += 1
 
     def set_padded_inputs(self, input_ids: torch.Tensor, pixel_values: torch.Tensor, attention_mask: torch.Tensor) -> None:
         """Right-padded prompts [B, L] with attention_mask [B, L] (1 = real token; the collator's layout,

@@ -207,7 +207,9 @@ class PrismaticForConditionalGeneration(PrismaticPreTrainedModel):
         return self._lru(self._engines, (batch, prompt_len, n_new, fp8, padded),
                          lambda: OpenVLAEngine(self.weights, batch, prompt_len, n_new=n_new, fp8=fp8 and not padded, padded=padded))
 
-    # ---- forward (multimodal prefill; logits for all positions) ----
+    # ---- forward: the reference's three branches (modeling_prismatic.py:322-415) ----
+    cache_new_tokens = 7       # tokens a `forward(..., use_cache=True)` KV cache is sized for (prefill token + 6 cached steps)
+
     @torch.no_grad()
     def forward(self, input_ids: Optional[torch.LongTensor] = None, attention_mask: Optional[torch.Tensor] = None,
                 pixel_values: Optional[torch.FloatTensor] = None, labels: Optional[torch.LongTensor] = None,
@@ -215,24 +217,69 @@ class PrismaticForConditionalGeneration(PrismaticPreTrainedModel):
                 use_cache: Optional[bool] = None, output_attentions: Optional[bool] = None,
                 output_hidden_states: Optional[bool] = None, output_projector_features: Optional[bool] = None,
                 return_dict: Optional[bool] = None) -> Union[Tuple, PrismaticCausalLMOutputWithPast]:
-        """Multimodal forward (modeling_prismatic.py:362-415): returns fp32 logits [B, 256+L, vocab] and, when `labels`
-        are given, the shifted mean cross-entropy over the valid tokens (HF CausalLM loss). Inference only in this
-        round: gradients, `inputs_embeds`, `output_attentions` and `output_hidden_states` are not provided."""
-        if inputs_embeds is not None or output_attentions or output_hidden_states:
-            raise NotImplementedError("inputs_embeds / output_attentions / output_hidden_states are not on the HIP path")
-        if input_ids is None or pixel_values is None:
-            raise ValueError("Invalid PrismaticForConditionalGeneration `forward()` call: need input_ids and pixel_values")
-        if input_ids.shape[0] != pixel_values.shape[0]:
-            raise ValueError("Non-homogenous batch of (text, image) input -- forward() does not support mixed batches!")
-        if past_key_values is not None:
-            raise NotImplementedError("cached generation is driven by predict_action()/generate() on this path")
-        from ...forward_full import forward_all_rows
-        loss, logits, proj = forward_all_rows(self, input_ids, attention_mask, pixel_values, labels)
-        out = PrismaticCausalLMOutputWithPast(loss=loss, logits=logits,
+        """The reference's forward (modeling_prismatic.py:291-447), branch for branch:
+
+          * cached generation — `input_ids [B, 1]` + `past_key_values` (:325-341; the batch-1 assert is lifted): one
+            decode step on the KV cache the handle names → logits [B, 1, vocab], the same handle one token longer;
+          * language-only forward — `pixel_values is None` (:343-359): fp32 logits [B, L, vocab] (+ loss); `inputs_embeds`
+            [B, L, D] may replace `input_ids` here (extension; the reference's own `inputs_embeds` plumbing is dead code,
+            SURVEY App. C.3);
+          * multimodal forward (:362-415): fp32 logits [B, 256+L, vocab] and, with `labels`, the shifted mean
+            cross-entropy over the valid tokens (HF CausalLM loss). With `use_cache=True` (and no labels) it is the FIRST
+            STEP OF GENERATION: the engine's generation plan runs — bit for bit the launches `generate()` replays — and
+            returns the last position's logits [B, 1, vocab] (what GenerationMixin consumes; `logits_to_keep=1` in
+            current transformers) plus an opaque `past_key_values` handle bound to that engine's KV caches.
+
+        `output_hidden_states=True` (all-position branches) returns HF's tuple: embeddings, every decoder layer's output,
+        the last one after the final norm. `output_attentions` cannot be served: the attention kernels never materialise
+        the probability matrix (neither does the reference under flash-attn). No gradients flow through this class."""
+        if output_attentions:
+            raise NotImplementedError("output_attentions: the fused attention kernels do not materialise attention weights")
+        if input_ids is None and inputs_embeds is None:
+            raise ValueError("Invalid PrismaticForConditionalGeneration `forward()` call: need input_ids (or inputs_embeds)")
+        from ...forward_full import EngineKVCache, forward_all_rows, forward_cached_step, forward_prefill_cached
+        hidden = proj = loss = None
+        cache: Optional[EngineKVCache] = None
+        if input_ids is not None and input_ids.shape[1] == 1:
+            assert past_key_values is not None, "You must provide `past_key_values` during cached generation!"
+            assert labels is None, "Unexpected key `labels` provided during cached generation!"
+            logits = forward_cached_step(self, input_ids, past_key_values)
+            cache = past_key_values
+        elif pixel_values is None:
+            assert past_key_values is None, "Unexpected key `past_key_values` provided during language-only forward!"
+            loss, logits, _, hidden = forward_all_rows(self, input_ids, attention_mask, None, labels, inputs_embeds,
+                                                      bool(output_hidden_states))
+        else:
+            if input_ids is None or input_ids.shape[0] != pixel_values.shape[0]:
+                raise ValueError("Non-homogenous batch of (text, image) input -- forward() does not support mixed batches!")
+            assert past_key_values is None, "Unexpected key `past_key_values` provided during language-only forward!"
+            if use_cache and labels is None and not output_hidden_states and not output_projector_features:
+                logits, cache = forward_prefill_cached(self, input_ids, attention_mask, pixel_values, self.cache_new_tokens)
+            else:
+                loss, logits, proj, hidden = forward_all_rows(self, input_ids, attention_mask, pixel_values, labels,
+                                                             inputs_embeds, bool(output_hidden_states))
+        out = PrismaticCausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache, hidden_states=hidden,
                                               projector_features=proj if output_projector_features else None)
         if return_dict is False:
             return out.to_tuple()
         return out
+
+    def prepare_inputs_for_generation(self, input_ids: Optional[torch.Tensor] = None, past_key_values: Optional[Any] = None,
+                                      inputs_embeds: Optional[torch.FloatTensor] = None,
+                                      pixel_values: Optional[torch.FloatTensor] = None,
+                                      attention_mask: Optional[torch.Tensor] = None, **kwargs: Any) -> Dict[str, Any]:
+        """modeling_prismatic.py:450-485 (GenerationMixin hook): with a cache only the newest token is fed; pixel values,
+        mask, cache and `use_cache` ride along. The batch-1 restriction of the reference (:460-463) is lifted, and its
+        dead `"input_embeds"` key is spelled `inputs_embeds`."""
+        if past_key_values is not None:
+            input_ids = input_ids[:, -1:]
+        if inputs_embeds is not None and past_key_values is None:
+            model_inputs: Dict[str, Any] = {"inputs_embeds": inputs_embeds}
+        else:
+            model_inputs = {"input_ids": input_ids}
+        model_inputs.update({"attention_mask": attention_mask, "pixel_values": None if past_key_values is not None else pixel_values,
+                             "past_key_values": past_key_values, "use_cache": kwargs.get("use_cache")})
+        return model_inputs
 
     # nn.Module.__call__ dispatches to forward()
 

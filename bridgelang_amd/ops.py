@@ -20,7 +20,7 @@ from ._lib import (AttnDesc, GemmDesc, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EP
                    EPI_RES, EPI_SWIGLU)
 
 __all__ = ["Op", "gemm", "gemm_fp8", "quantize_rows_fp8", "quantize_weight_fp8", "pack_weight", "unpack_weight", "cross_entropy", "layernorm", "rmsnorm", "rmsnorm_skinny", "skinny_rows_supported", "attention", "attention_rope", "attention_decode", "attention_decode_rope", "attention_decode_rope_grouped", "skinny_supported", "rope_kvcache", "embed_splice",
-           "argmax", "im2col_patch14", "preprocess_u8", "resample_coeffs", "resize_bicubic_u8", "write_prefix_tokens", "fill_synth", "run_all",
+           "argmax", "im2col_patch14", "preprocess_u8", "resample_coeffs", "resize_bicubic_u8", "resize_u8", "crop_resize_bilinear_u8", "write_prefix_tokens", "fill_synth", "run_all",
            "EPI_NONE", "EPI_BIAS", "EPI_BIAS_GELU", "EPI_BIAS_RES", "EPI_RES", "EPI_SWIGLU", "EPI_F32", "EPI_F32_BF16R"]
 
 
@@ -542,14 +542,29 @@ def _bicubic(x: float) -> float:
     return 0.0
 
 
+def _lanczos(x: float) -> float:
+    """Pillow's Lanczos-3 kernel (Resample.c lanczos_filter: truncated sinc, support 3)."""
+    def sinc(v: float) -> float:
+        if v == 0.0:
+            return 1.0
+        v = v * math.pi
+        return math.sin(v) / v
+    return sinc(x) * sinc(x / 3) if -3.0 <= x < 3.0 else 0.0
+
+
+_FILTERS = {"bicubic": (_bicubic, 2.0), "lanczos": (_lanczos, 3.0)}
+
+
 @functools.lru_cache(maxsize=64)
-def resample_coeffs(in_size: int, out_size: int):
-    """Pillow's coefficient table for one axis of an 8-bit bicubic resize (libImaging/Resample.c precompute_coeffs +
-    normalize_coeffs_8bpc, whole-image box): (bounds int32 [out, 2] = first tap / tap count, coefs int32 [out, ksize],
-    ksize). Doubles throughout, in Pillow's operation order; 22-bit fixed point, rounded half away from zero."""
+def resample_coeffs(in_size: int, out_size: int, filter: str = "bicubic"):
+    """Pillow's coefficient table for one axis of an 8-bit separable resize (libImaging/Resample.c precompute_coeffs +
+    normalize_coeffs_8bpc, whole-image box) with the bicubic (a = -0.5, support 2) or Lanczos-3 filter: (bounds int32
+    [out, 2] = first tap / tap count, coefs int32 [out, ksize], ksize). Doubles throughout, in Pillow's operation order;
+    22-bit fixed point, rounded half away from zero."""
+    kernel, base_support = _FILTERS[filter]
     scale = in_size / out_size
     filterscale = max(scale, 1.0)
-    support = 2.0 * filterscale
+    support = base_support * filterscale
     ksize = int(math.ceil(support)) * 2 + 1
     bounds = torch.zeros(out_size, 2, dtype=torch.int32)
     coefs = torch.zeros(out_size, ksize, dtype=torch.int32)
@@ -558,7 +573,7 @@ def resample_coeffs(in_size: int, out_size: int):
         center = 0.0 + (xx + 0.5) * scale
         xmin = max(int(center - support + 0.5), 0)
         xmax = min(int(center + support + 0.5), in_size) - xmin
-        w = [_bicubic((x + xmin - center + 0.5) * inv) for x in range(xmax)]
+        w = [kernel((x + xmin - center + 0.5) * inv) for x in range(xmax)]
         ww = 0.0
         for v in w:
             ww += v
@@ -573,20 +588,20 @@ def resample_coeffs(in_size: int, out_size: int):
 _COEF_DEV: dict = {}
 
 
-def resize_bicubic_u8(frames: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
+def resize_u8(frames: torch.Tensor, out_h: int, out_w: int, filter: str = "bicubic") -> torch.Tensor:
     """uint8 frames [B, H, W, 3] on the GPU → [B, out_h, out_w, 3], bit-identical to PIL `Image.resize((out_w, out_h),
-    BICUBIC)` per frame: horizontal pass, uint8 intermediate, vertical pass (a pass whose size does not change is
-    skipped, as in Pillow)."""
+    BICUBIC | LANCZOS)` per frame: horizontal pass, uint8 intermediate, vertical pass (a pass whose size does not change
+    is skipped, as in Pillow)."""
     lib = _lib.load()
     if frames.dtype != torch.uint8 or not frames.is_cuda or not frames.is_contiguous() or frames.dim() != 4 or frames.shape[-1] != 3:
-        raise TypeError("resize_bicubic_u8: frames must be a contiguous CUDA/HIP uint8 tensor [B, H, W, 3]")
+        raise TypeError("resize_u8: frames must be a contiguous CUDA/HIP uint8 tensor [B, H, W, 3]")
     B, H, W, _ = frames.shape
     cur = frames
 
     def tables(n_in, n_out):
-        key = (n_in, n_out, frames.device)
+        key = (n_in, n_out, filter, frames.device)
         if key not in _COEF_DEV:
-            b, c, ks = resample_coeffs(n_in, n_out)
+            b, c, ks = resample_coeffs(n_in, n_out, filter)
             _COEF_DEV[key] = (b.to(frames.device), c.to(frames.device), ks)
         return _COEF_DEV[key]
 
@@ -603,6 +618,32 @@ def resize_bicubic_u8(frames: torch.Tensor, out_h: int, out_w: int) -> torch.Ten
                                                              c.data_ptr(), ks), (cur, dst, b, c)).run()
         cur = dst
     return cur
+
+
+def resize_bicubic_u8(frames: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
+    return resize_u8(frames, out_h, out_w, "bicubic")
+
+
+def crop_resize_bilinear_u8(frames: torch.Tensor, y_base: float, y_step: float, x_base: float, x_step: float,
+                            out_h: int, out_w: int, out: Optional[torch.Tensor] = None, run: bool = True):
+    """tf.image.crop_and_resize (+ the uint8 ↔ float32 conversions around it) of the eval-time centre crop
+    (experiments/robot/openvla_utils.py:81-155) on uint8 frames [B, H, W, 3] in HBM; the four fp32 sampling constants
+    come from the caller (vla/eval_preprocess.py computes them exactly as its host restatement does)."""
+    lib = _lib.load()
+    if frames.dtype != torch.uint8 or not frames.is_cuda or not frames.is_contiguous() or frames.dim() != 4 or frames.shape[-1] != 3:
+        raise TypeError("crop_resize_bilinear_u8: frames must be a contiguous CUDA/HIP uint8 tensor [B, H, W, 3]")
+    B, H, W, _ = frames.shape
+    if out is None:
+        out = torch.empty(B, out_h, out_w, 3, dtype=torch.uint8, device=frames.device)
+    elif tuple(out.shape) != (B, out_h, out_w, 3) or out.dtype != torch.uint8 or not out.is_contiguous():
+        raise ValueError(f"crop_resize_bilinear_u8: out must be contiguous uint8 [{B}, {out_h}, {out_w}, 3]")
+    op = Op("bl_crop_resize_bilinear_u8", lib.bl_crop_resize_bilinear_u8,
+            (frames.data_ptr(), out.data_ptr(), B, H, W, out_h, out_w, float(y_base), float(y_step), float(x_base), float(x_step)),
+            (frames, out), nbytes=B * (H * W + out_h * out_w) * 3.0)
+    if run:
+        op.run()
+        return out
+    return op
 
 
 def fill_synth(dst: torch.Tensor, seed: int, mean: float, scale: float, *, rows: Optional[int] = None,

@@ -10,7 +10,12 @@
 The reference runs both through TensorFlow, which is absent here and on the GPU box: the arithmetic below restates the
 TF ops' documented definitions with numpy / Pillow (JPEG codec and Lanczos filter are Pillow's, TF's differ in rounding
 details) — PARITY UNPINNED against TF; the tests check the defining properties (geometry, identity cases, value ranges).
-Frames then go through `PrismaticImageProcessor` (bit-exact vs Pillow, on the CPU or on the GPU)."""
+Frames then go through `PrismaticImageProcessor` (bit-exact vs Pillow, on the CPU or on the GPU).
+
+Device twins for uint8 frames already in HBM (SURVEY §8(f)2 "as a GPU kernel (K1) fed by uint8 frames"):
+`center_crop_and_resize_gpu` (bl_crop_resize_bilinear_u8, bit-identical to `center_crop_and_resize` below) and
+`lanczos_resize_gpu` (bl_resample_pass_u8 with Lanczos-3 tables, bit-identical to Pillow's `Image.resize(LANCZOS)`, the
+resize half of `resize_image`). The JPEG round trip is an entropy codec, not a throughput kernel: it stays on the host."""
 from __future__ import annotations
 
 import io
@@ -28,6 +33,45 @@ def _to_float(img_u8: np.ndarray) -> np.ndarray:
 def _to_uint8_saturate(img_f: np.ndarray) -> np.ndarray:
     """tf.image.convert_image_dtype(float32 → uint8, saturate=True): x * (255 + 0.5), saturate, truncate."""
     return np.clip(img_f * np.float32(255.5), 0.0, 255.0).astype(np.uint8)
+
+
+def sampling_constants(box: Tuple[float, float, float, float], hw: Tuple[int, int], out_hw: Tuple[int, int]):
+    """The four fp32 constants of `crop_and_resize_bilinear`'s sampling grid: ys[i] = y_base + i·y_step (xs likewise),
+    each rounded to fp32 exactly where numpy rounds it (a python-float scalar meeting a float32 array)."""
+    (H, W), (oh, ow), (y1, x1, y2, x2) = hw, out_hw, box
+    f = lambda v: float(np.float32(v))
+    if oh == 1:
+        y_base, y_step = f(0.5 * (y1 + y2) * (H - 1)), 0.0
+    else:
+        y_base, y_step = f(y1 * (H - 1)), f((y2 - y1) * (H - 1) / max(oh - 1, 1))
+    if ow == 1:
+        x_base, x_step = f(0.5 * (x1 + x2) * (W - 1)), 0.0
+    else:
+        x_base, x_step = f(x1 * (W - 1)), f((x2 - x1) * (W - 1) / max(ow - 1, 1))
+    return y_base, y_step, x_base, x_step
+
+
+def center_crop_box(crop_scale: float) -> Tuple[float, float, float, float]:
+    side = float(np.clip(np.sqrt(crop_scale), 0.0, 1.0))
+    off = (1.0 - side) / 2.0
+    return (off, off, off + side, off + side)
+
+
+def center_crop_and_resize_gpu(frames_u8, crop_scale: float = 0.9, out_hw: Tuple[int, int] = (224, 224)):
+    """`center_crop_and_resize` for a batch of uint8 frames [B, H, W, 3] resident on the GPU → uint8 [B, out_h, out_w, 3]
+    (one HBM-bound kernel, bl_crop_resize_bilinear_u8); bit-identical to the host function below, frame by frame."""
+    from .. import ops
+    B, H, W, _ = frames_u8.shape
+    yb, ys, xb, xs = sampling_constants(center_crop_box(crop_scale), (H, W), out_hw)
+    return ops.crop_resize_bilinear_u8(frames_u8, yb, ys, xb, xs, out_hw[0], out_hw[1])
+
+
+def lanczos_resize_gpu(frames_u8, resize_size: Tuple[int, int]):
+    """The resize half of `resize_image` for uint8 frames [B, H, W, 3] on the GPU: Pillow's 8-bit Lanczos-3 resample as
+    two bl_resample_pass_u8 passes, bit-identical to `Image.resize((w, h), Image.LANCZOS)`."""
+    from .. import ops
+    h, w = resize_size
+    return ops.resize_u8(frames_u8, h, w, "lanczos")
 
 
 def crop_and_resize_bilinear(img_f: np.ndarray, box: Tuple[float, float, float, float], out_hw: Tuple[int, int]) -> np.ndarray:
@@ -54,9 +98,7 @@ def crop_and_resize_bilinear(img_f: np.ndarray, box: Tuple[float, float, float, 
 
 def center_crop_and_resize(image_u8: np.ndarray, crop_scale: float = 0.9, out_hw: Tuple[int, int] = (224, 224)) -> np.ndarray:
     """openvla_utils.py:127-155: uint8 [H, W, 3] → uint8 [out_h, out_w, 3]; the crop keeps sqrt(crop_scale) of each side."""
-    side = float(np.clip(np.sqrt(crop_scale), 0.0, 1.0))
-    off = (1.0 - side) / 2.0
-    out = crop_and_resize_bilinear(_to_float(np.asarray(image_u8)), (off, off, off + side, off + side), out_hw)
+    out = crop_and_resize_bilinear(_to_float(np.asarray(image_u8)), center_crop_box(crop_scale), out_hw)
     return _to_uint8_saturate(np.clip(out, 0.0, 1.0))
 
 

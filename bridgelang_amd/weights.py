@@ -119,7 +119,8 @@ class TensorSpec:
     row0: int = 0
 
 
-RECIPES = ("init", "decisive")
+RECIPES = ("init", "decisive", "margin")
+MARGIN_BRANCH_SCALE = 1.0 / 16.0     # "margin": residual branches this much smaller again than "decisive"'s
 
 
 def tensor_seed(name: str, seed: int) -> int:
@@ -193,7 +194,16 @@ def tensor_specs(d: VLADims, recipe: str = "init") -> List[TensorSpec]:
     which a trained checkpoint is not. It differs from "init" in three std values: residual-branch output projections
     (attn.proj / mlp.fc2 / o_proj / down_proj) are scaled by 1/sqrt(2·depth) (GPT-2 style), token embeddings have unit
     std (they then carry the stream), and — as an overlay, synthetic_overlays() — the lm_head rows of the 256 action
-    tokens are 6x larger, so greedy decoding lands in the action vocabulary as a fine-tuned OpenVLA does."""
+    tokens are 6x larger, so greedy decoding lands in the action vocabulary as a fine-tuned OpenVLA does.
+
+    recipe="margin" is "decisive" with every residual branch a further 16x smaller (MARGIN_BRANCH_SCALE). Between two
+    correct fp32 summation orders the relative difference of the residual stream grows by about 0.0024 x (branch / stream
+    ratio) per residual add (each re-rounding of the stream to bf16 turns the branch's small difference into rare
+    whole-ulp flips; DESIGN.md §4 "noise floor"), so on this checkpoint the logit noise falls to about one bf16 ulp of
+    the logit scale — small enough that sequences whose oracle top-2 gap is >= 3x that noise at all 7 steps exist and
+    can be selected (tests/golden/make_margin_b16.py): the fixture on which the WHOLE [16, 7] id matrix must be
+    bit-exact. The price: the stream is dominated by the token / patch embeddings, so ids depend on the inputs only
+    weakly; input sensitivity is what the "init" / "decisive" fixtures and the per-op full-size tests cover."""
     if recipe not in RECIPES:
         raise ValueError(f"unknown synthetic recipe {recipe!r}")
     out = list(_tower_specs(d.dino)) + list(_tower_specs(d.siglip))
@@ -214,13 +224,14 @@ def tensor_specs(d: VLADims, recipe: str = "init") -> List[TensorSpec]:
         out.append(TensorSpec(f"{b}.mlp.down_proj.weight", (L, d.llm_inter), 0.0, 0.02))
     out.append(TensorSpec(f"{lm}.norm.weight", (L,), 1.0, 0.02))
     out.append(TensorSpec("language_model.lm_head.weight", (d.vocab, L), 0.0, 0.02))
-    if recipe == "decisive":
+    if recipe in ("decisive", "margin"):
+        extra = MARGIN_BRANCH_SCALE if recipe == "margin" else 1.0
         depth = {d.dino.prefix: d.dino.n_run, d.siglip.prefix: d.siglip.n_run, "language_model": d.llm_layers}
 
         def adjust(sp: TensorSpec) -> TensorSpec:
             if sp.name.endswith((".attn.proj.weight", ".mlp.fc2.weight", ".o_proj.weight", ".down_proj.weight")):
                 n = next(v for k, v in depth.items() if sp.name.startswith(k))
-                return TensorSpec(sp.name, sp.shape, sp.mean, sp.std / (2.0 * n) ** 0.5)
+                return TensorSpec(sp.name, sp.shape, sp.mean, sp.std * extra / (2.0 * n) ** 0.5)
             if sp.name.endswith("embed_tokens.weight"):
                 return TensorSpec(sp.name, sp.shape, 0.0, 1.0)
             return sp
@@ -234,8 +245,8 @@ TOKENIZER_VOCAB = 32000    # Llama-2 tokenizer size; the padded embedding has d.
 
 def synthetic_overlays(d: VLADims, recipe: str = "init") -> List[TensorSpec]:
     """Row blocks generated separately and written over part of a base tensor (synthetic checkpoints only; they are not
-    tensors of the state dict). "decisive": the lm_head rows of the action tokens."""
-    if recipe != "decisive" or d.vocab < TOKENIZER_VOCAB:
+    tensors of the state dict). "decisive" / "margin": the lm_head rows of the action tokens."""
+    if recipe not in ("decisive", "margin") or d.vocab < TOKENIZER_VOCAB:
         return []
     return [TensorSpec("language_model.lm_head.weight#action_rows", (N_ACTION_TOKENS, d.llm_dim), 0.0, 0.12,
                        base="language_model.lm_head.weight", row0=TOKENIZER_VOCAB - N_ACTION_TOKENS)]

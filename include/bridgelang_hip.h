@@ -336,6 +336,14 @@ int bl_preprocess_u8_bf16(const uint8_t* frames, int32_t B, int32_t height, int3
  * dst [B, out_len, lines, 3]. uint8 RGB, packed. Bit-exact against Pillow (tests/test_ops_gpu.py). */
 int bl_resample_pass_u8(const uint8_t* src, uint8_t* dst, int32_t B, int32_t lines, int32_t in_len, int32_t out_len,
                         int32_t horizontal, const int32_t* bounds, const int32_t* coefs, int32_t ksize, void* stream);
+/* The eval-time centre crop of the robot loops, `get_vla_action(center_crop=True)` (experiments/robot/openvla_utils.py:
+ * 81-155: tf.image.convert_image_dtype → tf.image.crop_and_resize(bilinear, one box) → clip → convert back, saturating):
+ * uint8 frames src [B, H, W, 3] → dst [B, out_h, out_w, 3]. Output pixel (i, j) samples ys = y_base + i·y_step,
+ * xs = x_base + j·x_step (fp32 constants computed by the host: y1·(H−1) and (y2−y1)·(H−1)/(out_h−1) for the normalised
+ * box), bilinear on u8/255, 0 outside the image, then uint8(clamp(clamp(v,0,1)·255.5, 0, 255)). Bit-identical to the host
+ * restatement bridgelang_amd/vla/eval_preprocess.py (TensorFlow itself is absent: unpinned against TF). */
+int bl_crop_resize_bilinear_u8(const uint8_t* src, uint8_t* dst, int32_t B, int32_t H, int32_t W, int32_t out_h, int32_t out_w,
+                               float y_base, float y_step, float x_base, float x_step, void* stream);
 /* pixel_values [B, 6, 224, 224] bf16 (processing_prismatic.py:128-145 layout) → 14x14 patch rows for one tower:
  * out[b*256 + py*16 + px, c*196 + i*14 + j] = pixel_values[b, chan0 + c, py*14 + i, px*14 + j]; columns 588..ld-1
  * are zeroed (K padded to a multiple of 64 for the patch-embed GEMM; timm PatchEmbed conv flattening order). */

@@ -1,0 +1,95 @@
+"""Build the full-size fixture on which the WHOLE id matrix must be bit-exact: 16 sequences on the "margin" synthetic
+checkpoint (bridgelang_amd/weights.py::tensor_specs) whose oracle top-2 gap is at least `--min-gap` of the logit scale at
+EVERY one of the 7 greedy steps — i.e. >= 3x the logit noise measured between two correct fp32 summation orders on this
+checkpoint (tests/golden/make_noise_floor_7b.py → noise_floor_7b_margin_b1_s0_tree8.npz).
+
+    python tests/golden/make_margin_b16.py --min-gap 0.03 [--first-seed 1000] [--max-candidates 320]
+
+Candidate sequence s is BASELINE configs[1]'s input recipe drawn alone: make_inputs(1, 32, seed=s) (one uniform-uint8 224 px
+frame, BOS + 30 uniform ids + 29871). Candidates go through oracle/restate.py (CPU, openvla-7b, greedy 7 tokens) 16 at a
+time; a candidate is kept when min over its 7 steps of (top-1 − top-2) / max|logit| >= --min-gap. The first 16 kept
+candidates, in seed order, are the fixture: their seeds, input ids, oracle ids, per-step gap and scale, and the oracle's
+top-32 logits per step (bf16 bit patterns). Data only; the selection is reproducible from the seeds.
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--recipe", default="margin")
+    ap.add_argument("--min-gap", type=float, required=True)
+    ap.add_argument("--first-seed", type=int, default=1000)
+    ap.add_argument("--max-candidates", type=int, default=320)
+    ap.add_argument("--want", type=int, default=16)
+    ap.add_argument("--group", type=int, default=16, help="candidates per oracle run")
+    ap.add_argument("--prompt-len", type=int, default=32)
+    ap.add_argument("--wseed", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--topk", type=int, default=32)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    torch.set_num_threads(args.threads)
+    torch.set_flush_denormal(True)
+    from bridgelang_amd import weights as W
+    from oracle import restate as R, synth as S
+    from test_full_size_gpu import make_inputs
+
+    dims = W.openvla_7b_dims()
+    t0 = time.time()
+    sd = S.synth_state_dict(W.tensor_specs(dims, args.recipe), seed=args.wseed, overlays=W.synthetic_overlays(dims, args.recipe))
+    print(f"checkpoint ({args.recipe}): {time.time() - t0:.0f} s", flush=True)
+    model = R.OracleModel.from_dims(sd, dims)
+    kept = []                  # (seed, input_ids [L], ids [7], gap [7], scale [7], topk vals [7,k], topk idx [7,k], pixel checksum)
+    seen = 0
+    seed = args.first_seed
+    while len(kept) < args.want and seen < args.max_candidates:
+        seeds = list(range(seed, seed + args.group))
+        seed += args.group
+        seen += args.group
+        pairs = [make_inputs(1, args.prompt_len, s) for s in seeds]
+        ids = torch.cat([p[0] for p in pairs]); pv = torch.cat([p[1] for p in pairs])
+        t0 = time.time()
+        with torch.no_grad():
+            gen, logits = model.generate(ids, pv, n_new=7, last_row_only=True)      # [G, 7], [G, 7, V]
+        top2 = logits.topk(2, dim=-1).values
+        scale = logits.abs().amax(dim=-1)
+        gap = (top2[..., 0] - top2[..., 1]) / scale
+        tk = logits.topk(args.topk, dim=-1)
+        ok = gap.amin(dim=1) >= args.min_gap
+        for j, s in enumerate(seeds):
+            if ok[j] and len(kept) < args.want:
+                p = pv[j].float().double()
+                kept.append((s, ids[j].numpy(), gen[j].numpy(), (gap[j] * scale[j]).numpy(), scale[j].numpy(),
+                             tk.values[j].to(torch.bfloat16).view(torch.int16).numpy(), tk.indices[j].numpy().astype(np.int32),
+                             np.array([p.sum().item(), p.abs().sum().item()])))
+        print(f"seeds {seeds[0]}..{seeds[-1]}: {time.time() - t0:.0f} s, min gap/scale per candidate "
+              f"{[round(v, 3) for v in gap.amin(dim=1).tolist()]} → kept {len(kept)}/{args.want} of {seen} "
+              f"(distinct first ids in this group: {len(set(gen[:, 0].tolist()))}, distinct id rows: {len(set(map(tuple, gen.tolist())))})",
+              flush=True)
+    if len(kept) < args.want:
+        raise SystemExit(f"only {len(kept)} of {args.want} candidates passed --min-gap {args.min_gap} among {seen}")
+    out = args.out or str(ROOT / "tests" / "golden" / f"cfg2_7b_{args.recipe}_b{args.want}_selected.npz")
+    col = lambda i: np.stack([k[i] for k in kept])
+    np.savez_compressed(out, seq_seeds=np.array([k[0] for k in kept], dtype=np.int64), input_ids=col(1), ids=col(2).astype(np.int64),
+                        top2_gap=col(3), logit_scale=col(4), topk_vals_bf16=col(5), topk_idx=col(6), pixel_checksum=col(7),
+                        min_gap=np.array(args.min_gap), candidates_seen=np.array(seen),
+                        meta=np.array([args.want, args.prompt_len, args.first_seed, args.wseed]), recipe=np.array(args.recipe))
+    g = col(3) / col(4)
+    print(f"wrote {out}: seeds {[k[0] for k in kept]}, min gap/scale over all {g.size} (sequence, step) pairs {g.min():.4f}, "
+          f"distinct id rows {len(set(map(tuple, col(2).tolist())))}")
+
+
+if __name__ == "__main__":
+    main()

@@ -150,3 +150,115 @@ def test_entry_scripts_run_two_steps_on_dummy_data(script, tmp_path):
         rows = [json.loads(l) for l in open(run / "smoke.jsonl")]
         assert rows[-1]["VLA Train/Step"] == 2 and np.isfinite(rows[-1]["VLA Train/Loss"])
         assert list((run / "checkpoints").glob("step-000002-epoch-*-loss=*.pt")) and (run / "dataset_statistics.json").exists()
+
+
+def _small_inputs(dev, B=3, L=12, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(3, 31743, (B, L), generator=g)
+    ids[:, 0], ids[:, -1] = 1, 29871
+    pv = (torch.rand(B, 6, 224, 224, generator=g) * 2 - 1).to(torch.bfloat16)
+    return ids.to(dev), pv.to(dev)
+
+
+def test_forward_step_by_step_reproduces_generate(saved, dev):
+    """The HF cached-forward surface (modeling_prismatic.py:325-341, 450-485): a caller that drives
+    forward() itself — multimodal call with use_cache=True, then one [B, 1] call per token with the returned
+    past_key_values, inputs built by prepare_inputs_for_generation — gets, bit for bit, the ids AND logits generate()
+    computes on-device."""
+    _, model = saved
+    ids, pv = _small_inputs(dev)
+    B, n = ids.shape[0], 7
+    want = model.generate(ids, max_new_tokens=n, pixel_values=pv)[:, -n:].clone()
+    eng = model.engine(B, ids.shape[1], n)
+    want_logits = eng.logits.clone()                                  # [n, B, V]
+    seq, past, got_logits = ids, None, []
+    for t in range(n):
+        kw = model.prepare_inputs_for_generation(seq, past_key_values=past, pixel_values=pv, attention_mask=None, use_cache=True)
+        out = model(**kw)
+        assert out.logits.shape == (B, 1, model.dims.vocab) and out.logits.dtype == torch.float32
+        past = out.past_key_values
+        assert past.get_seq_length() == eng.S + t
+        got_logits.append(out.logits[:, -1])
+        seq = torch.cat([seq, out.logits[:, -1].argmax(-1, keepdim=True)], dim=1)
+    assert torch.equal(seq[:, -n:], want), "step-wise forward() must reproduce generate()'s ids"
+    assert torch.equal(torch.stack(got_logits), want_logits), "… and its logits, bit for bit"
+    # a token other than the model's own argmax can be fed (teacher forcing): the cache really is driven by the caller
+    out0 = model(input_ids=ids, pixel_values=pv, use_cache=True)
+    forced = torch.full((B, 1), 31900, dtype=torch.long, device=dev)
+    o1 = model(input_ids=forced, past_key_values=out0.past_key_values, use_cache=True)
+    ref = model.generate(torch.cat([ids, forced], 1), max_new_tokens=1, pixel_values=pv)[:, -1]
+    # (prefill over L+1 tokens vs cached step: different kernels → compare ids only where the gap is decisive)
+    top2 = o1.logits[:, -1].topk(2, -1).values
+    decisive = (top2[:, 0] - top2[:, 1]) > 0.05 * o1.logits.abs().max()
+    assert torch.equal(o1.logits[:, -1].argmax(-1)[decisive], ref[decisive])
+    # guards: capacity, stale handles, missing cache
+    with pytest.raises(AssertionError):
+        model(input_ids=forced, use_cache=True)
+    stale = out0.past_key_values
+    model(input_ids=ids, pixel_values=pv, use_cache=True)             # same engine slot prefilled again
+    with pytest.raises(RuntimeError, match="stale"):
+        model(input_ids=forced, past_key_values=stale)
+    fresh = model(input_ids=ids, pixel_values=pv, use_cache=True).past_key_values
+    for _ in range(model.cache_new_tokens - 1):
+        model(input_ids=forced, past_key_values=fresh)
+    with pytest.raises(RuntimeError, match="sized for"):
+        model(input_ids=forced, past_key_values=fresh)
+
+
+def test_forward_padded_prefill_then_cached_steps(saved, dev):
+    """Right-padded batch through the step-wise surface ≡ generate() on the same padded batch."""
+    _, model = saved
+    ids, pv = _small_inputs(dev, B=2, L=14, seed=3)
+    mask = torch.ones_like(ids)
+    mask[1, 10:] = 0
+    ids[1, 9] = 29871
+    ids[1, 10:] = model.pad_token_id
+    n = 5
+    want = model.generate(ids, max_new_tokens=n, pixel_values=pv, attention_mask=mask)[:, -n:].clone()
+    model.cache_new_tokens = n
+    try:
+        out = model(input_ids=ids, pixel_values=pv, attention_mask=mask, use_cache=True)
+        toks = [out.logits[:, -1].argmax(-1)]
+        for _ in range(n - 1):
+            out = model(input_ids=toks[-1][:, None], past_key_values=out.past_key_values, use_cache=True)
+            toks.append(out.logits[:, -1].argmax(-1))
+    finally:
+        model.cache_new_tokens = 7
+    assert torch.equal(torch.stack(toks, 1), want)
+
+
+def test_forward_language_only_inputs_embeds_and_hidden_states(saved, dev):
+    """Language-only branch (pixel_values=None, modeling_prismatic.py:343-359) against the CPU oracle's Llama; the
+    `inputs_embeds` form equals the `input_ids` form bit for bit; `output_hidden_states` returns HF's tuple."""
+    from oracle import restate as R
+    _, model = saved
+    d = model.dims
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(3, 31743, (2, 9), generator=g)
+    ids[:, 0] = 1
+    labels = ids.clone()
+    labels[:, :4] = -100
+    out = model(input_ids=ids.to(dev), labels=labels.to(dev), output_hidden_states=True)
+    assert out.logits.shape == (2, 9, d.vocab) and out.past_key_values is None and out.projector_features is None
+    assert len(out.hidden_states) == d.llm_layers + 1 and out.hidden_states[0].shape == (2, 9, d.llm_dim)
+    sd = {k: v.cpu() for k, v in model.state_dict().items() if k.startswith("language_model.")}
+    p = R.Prec(True)
+    x = sd["language_model.model.embed_tokens.weight"].float()[ids]
+    assert torch.equal(out.hidden_states[0].float().cpu(), x)
+    tr = []
+    ref, _ = R.llama_forward(p, sd, x, d.llm_heads, d.llm_layers, d.rms_eps, d.rope_theta, trace=tr)
+    scale = ref.abs().max()
+    assert ((out.logits.cpu() - ref).abs().max() / scale) < 1.2e-2          # 2-layer bound of test_engine_gpu.py
+    for l in range(d.llm_layers - 1):
+        a, b = out.hidden_states[l + 1].float().cpu(), tr[l]
+        assert ((a - b).abs().max() / b.abs().max()) < 1.2e-2
+    last = R.rmsnorm(p, tr[-1], sd["language_model.model.norm.weight"].float(), d.rms_eps)
+    assert ((out.hidden_states[-1].float().cpu() - last).abs().max() / last.abs().max()) < 1.2e-2
+    # shifted CE (HF CausalLM loss) on the oracle's logits
+    want_loss = torch.nn.functional.cross_entropy(ref[:, :-1].reshape(-1, d.vocab), labels[:, 1:].reshape(-1), ignore_index=-100)
+    assert abs(float(out.loss) - float(want_loss)) < 2e-2
+    emb = model.weights.embed[ids.to(dev)]
+    out2 = model(inputs_embeds=emb)
+    assert torch.equal(out2.logits, out.logits)
+    with pytest.raises(NotImplementedError):
+        model(input_ids=ids.to(dev), output_attentions=True)

@@ -321,3 +321,41 @@ def test_resample_coefficient_tables_match_pillow(H, W):
     got = RS.two_pass(frames, tw, th)
     want = RS.pil_resize(frames, 224, 224)
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("H,W,oh,ow", [(256, 256, 224, 224), (480, 640, 224, 224), (128, 128, 224, 224), (224, 300, 224, 224), (256, 256, 128, 160)])
+def test_lanczos_coefficient_tables_match_pillow(H, W, oh, ow):
+    """The Lanczos-3 tables (ops.resample_coeffs(filter="lanczos"), the host half of the device twin of LIBERO's
+    resize_image, libero_utils.py:33-47) through the numpy restatement of the two 8-bit passes ≡ Pillow's
+    `Image.resize(LANCZOS)` bit for bit."""
+    from PIL import Image
+    from bridgelang_amd import ops
+    from oracle import resample as RS
+    rng = np.random.default_rng(H * 31 + W)
+    frames = rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+    frames[1, : H // 2] = 255
+    frames[1, H // 2:] = 0
+    tw = None if W == ow else tuple(t.numpy() for t in ops.resample_coeffs(W, ow, "lanczos")[:2])
+    th = None if H == oh else tuple(t.numpy() for t in ops.resample_coeffs(H, oh, "lanczos")[:2])
+    got = RS.two_pass(frames, tw, th)
+    want = np.stack([np.asarray(Image.fromarray(f).resize((ow, oh), Image.LANCZOS), dtype=np.uint8) for f in frames])
+    assert np.array_equal(got, want)
+
+
+def test_crop_sampling_constants_reproduce_the_host_grid():
+    """eval_preprocess.sampling_constants (what bl_crop_resize_bilinear_u8 is launched with) regenerates, in fp32, the
+    sampling grid of the host restatement of tf.image.crop_and_resize for the centre-crop box."""
+    from bridgelang_amd.vla import eval_preprocess as EP
+    for (H, W), out_hw, cs in (((256, 256), (224, 224), 0.9), ((480, 640), (224, 224), 0.9), ((224, 224), (224, 224), 1.0),
+                               ((100, 77), (13, 1), 0.5)):
+        box = EP.center_crop_box(cs)
+        yb, ys, xb, xs = EP.sampling_constants(box, (H, W), out_hw)
+        oh, ow = out_hw
+        y1, x1, y2, x2 = box
+        want_y = y1 * (H - 1) + np.arange(oh, dtype=np.float32) * ((y2 - y1) * (H - 1) / max(oh - 1, 1))
+        want_x = x1 * (W - 1) + np.arange(ow, dtype=np.float32) * ((x2 - x1) * (W - 1) / max(ow - 1, 1))
+        if ow == 1:
+            want_x = np.array([0.5 * (x1 + x2) * (W - 1)], dtype=np.float32)
+        got_y = np.float32(yb) + np.arange(oh, dtype=np.float32) * np.float32(ys)
+        got_x = np.float32(xb) + np.arange(ow, dtype=np.float32) * np.float32(xs)
+        assert np.array_equal(got_y, want_y) and np.array_equal(got_x, want_x)

@@ -1,0 +1,79 @@
+"""The noise floor between two CORRECT fp32 summation orders at full openvla-7b size.
+
+tests/golden/noise_floor_7b_<recipe>_b1_s0_tree8.npz (written by tests/golden/make_noise_floor_7b.py in the build
+container) holds the oracle run a second time with every nn.Linear's K contraction summed as 8 slices + a balanced tree
+instead of the CPU BLAS order — same weights, inputs and bf16 rounding points, teacher-forced on the first run's ids. The
+first run is the committed cfg1_7b_<recipe>_b1_s0.npz fixture itself. This test re-derives the oracle-vs-oracle′ figures
+from the two sets of logits, prints the table DESIGN.md §4 quotes, and pins the two facts the GPU parity bounds rest on:
+
+  * on "init" / "decisive" two correct orders differ by 2-4 % of the logit scale and share < 10 % of their logit bits —
+    so the HIP path's 2.8-3.9 % against the oracle is the floor, not kernel error (tests/test_cfg_7b_golden_gpu.py
+    bounds the HIP path at 1.5 x these figures);
+  * on "margin" the floor is below 1 % of the scale, which is what makes a whole-matrix id assertion well-posed there.
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def _bits(a: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(a.astype(np.int16)).view(torch.bfloat16).float()
+
+
+def load_noise_floor(recipe: str):
+    """→ (primary logits [1,7,V], alt logits [1,7,V], npz). Shared with the GPU test (bounds = 1.5 x measured floor)."""
+    z = np.load(GOLD / f"noise_floor_7b_{recipe}_b1_s0_tree8.npz")
+    alt = _bits(z["logits_bf16"])
+    prim_file = GOLD / f"cfg1_7b_{recipe}_b1_s0.npz"
+    if prim_file.exists():
+        p = np.load(prim_file)
+        assert np.array_equal(p["ids"], z["primary_ids"]), "noise-floor fixture was not made from the committed primary run"
+        prim = _bits(p["logits_bf16"])
+    else:
+        prim = _bits(z["primary_logits_bf16"])
+    return prim, alt, z
+
+
+def floor_of(recipe: str) -> float:
+    prim, alt, _ = load_noise_floor(recipe)
+    return float(((alt - prim).abs().amax(-1) / prim.abs().amax(-1)).max())
+
+
+@pytest.mark.parametrize("recipe,lo,hi,max_biteq", [("init", 2.5e-2, 5e-2, 0.10), ("decisive", 1.5e-2, 4e-2, 0.12), ("margin", 2e-3, 9e-3, 0.6)])
+def test_oracle_vs_oracle_in_a_second_summation_order(recipe, lo, hi, max_biteq):
+    prim, alt, z = load_noise_floor(recipe)
+    assert prim.shape == alt.shape == (1, 7, 32064) and str(z["order"]) == "tree8" and str(z["recipe"]) == recipe
+    scale = prim.abs().amax(-1)
+    dmax = ((alt - prim).abs().amax(-1) / scale)[0]
+    biteq = (alt == prim).float().mean(-1)[0]
+    assert np.allclose(dmax.numpy(), z["max_dlogit_over_scale"], rtol=1e-6) and np.allclose(biteq.numpy(), z["bit_equal"], rtol=1e-6)
+    assert np.array_equal(alt.argmax(-1).numpy(), z["ids"])
+    top2 = prim.topk(2, -1).values
+    gap = ((top2[..., 0] - top2[..., 1]) / scale)[0]
+    ids_equal = bool(np.array_equal(z["ids"], z["primary_ids"]))
+    print(f"\noracle[blas] vs oracle[tree8], openvla-7b '{recipe}', cfg 1 (B = 1, 7 greedy steps):")
+    print(f"  max |dlogit| / scale per step : {[f'{v:.2e}' for v in dmax.tolist()]}  (max {dmax.max():.2e})")
+    print(f"  bit-equal logits per step     : {[f'{v:.3f}' for v in biteq.tolist()]}")
+    print(f"  oracle top-2 gap / scale      : {[f'{v:.3f}' for v in gap.tolist()]};  ids equal: {ids_equal}")
+    for k in ("dino", "siglip", "projector", "llm"):
+        d = z[f"drift_{k}"]
+        pts = ", ".join(f"{v:.1e}" for v in d[:: max(1, len(d) // 6)])
+        print(f"  residual-stream relative rms drift, {k:9s} ({len(d):2d} taps): {pts} … last {d[-1]:.1e}")
+    assert lo <= float(dmax.max()) <= hi, "the measured floor moved out of the band DESIGN.md §4 documents"
+    assert float(biteq.max()) <= max_biteq
+    # every step whose oracle gap exceeds 2 x the floor must keep its id between the two orders
+    safe = gap > 2 * float(dmax.max())
+    assert np.array_equal(z["ids"][0][safe.numpy()], z["primary_ids"][0][safe.numpy()])
+    # drift grows monotonically on the whole (first tap below last tap) in every stack: accumulation, not a single bad op
+    for k in ("dino", "siglip", "llm"):
+        assert z[f"drift_{k}"][0] < z[f"drift_{k}"][-1]
+
+
+def test_margin_checkpoint_floor_is_far_below_the_others():
+    f = {r: floor_of(r) for r in ("init", "decisive", "margin")}
+    print(f"\nnoise floor (max |dlogit| / scale over 7 steps): {f}")
+    assert f["margin"] < f["decisive"] / 3 < f["init"]

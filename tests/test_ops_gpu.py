@@ -523,6 +523,45 @@ def test_resize_bicubic_frames_bit_exact(dev, H, W):
     assert torch.equal(ip.preprocess_frames_gpu(F).cpu(), ref)
 
 
+@pytest.mark.parametrize("H,W,out_hw,crop_scale", [(256, 256, (224, 224), 0.9), (480, 640, (224, 224), 0.9), (224, 224, (224, 224), 1.0),
+                                                   (128, 96, (224, 224), 0.5), (720, 1280, (224, 224), 0.9), (100, 77, (13, 1), 0.5),
+                                                   (64, 64, (224, 224), 1.3)])
+def test_center_crop_and_resize_device_twin_bit_exact(dev, H, W, out_hw, crop_scale):
+    """bl_crop_resize_bilinear_u8 (eval-time centre crop of the robot loops, experiments/robot/openvla_utils.py:81-155)
+    ≡ the host restatement of tf.image.crop_and_resize + convert_image_dtype, bit for bit, on uint8 frames in HBM
+    (TensorFlow itself is absent: the restatement is unpinned against TF, the kernel is pinned against the restatement)."""
+    from bridgelang_amd.vla import eval_preprocess as EP
+    rng = np.random.default_rng(H * 131 + W)
+    frames = rng.integers(0, 256, (3, H, W, 3), dtype=np.uint8)
+    frames[1, : H // 2] = 255
+    frames[1, H // 2:] = 0
+    frames[2, :, ::2] = 0
+    want = np.stack([EP.center_crop_and_resize(f, crop_scale, out_hw) for f in frames])
+    got = EP.center_crop_and_resize_gpu(torch.from_numpy(frames).to(dev), crop_scale, out_hw)
+    assert got.dtype == torch.uint8 and tuple(got.shape) == (3, out_hw[0], out_hw[1], 3)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("H,W,size", [(256, 256, (224, 224)), (480, 640, (224, 224)), (128, 128, (224, 224)), (224, 300, (224, 224)), (256, 256, (128, 160))])
+def test_lanczos_resize_device_twin_bit_exact(dev, H, W, size):
+    """The resize half of LIBERO's resize_image (libero_utils.py:33-47) on the device: bl_resample_pass_u8 with Lanczos-3
+    tables ≡ Pillow's `Image.resize(LANCZOS)` — the library the host restatement calls — bit for bit; with the JPEG
+    round trip done on the host the whole function matches."""
+    from PIL import Image
+    from bridgelang_amd.vla import eval_preprocess as EP
+    rng = np.random.default_rng(H * 17 + W)
+    frames = rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+    frames[1, : H // 2] = 255
+    frames[1, H // 2:] = 0
+    h, w = size
+    want = np.stack([np.asarray(Image.fromarray(f).resize((w, h), Image.LANCZOS), dtype=np.uint8) for f in frames])
+    got = EP.lanczos_resize_gpu(torch.from_numpy(frames).to(dev), size)
+    assert np.array_equal(got.cpu().numpy(), want)
+    jp = np.stack([EP.jpeg_round_trip(f) for f in frames])
+    assert np.array_equal(EP.lanczos_resize_gpu(torch.from_numpy(jp).to(dev), size).cpu().numpy(),
+                          np.stack([EP.resize_image(f, size) for f in frames]))
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(288, 12288, 4096, "none"), (288, 4096, 1024, "res"), (261, 1024, 4096, "res"), (256, 4352, 1152, "gelu"),
                                        (100, 192, 512, "gelu"), (33, 64, 1536, "none"), (320, 3072, 1536, "swiglu"), (288, 256, 1088, "res"),
                                        (576, 4096, 1024, "res"), (640, 12288, 512, "none"), (522, 1024, 1024, "gelu"), (161, 32064, 512, "none"),
