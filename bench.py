@@ -55,6 +55,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--no-graph", action="store_true", help="replay the op plan eagerly instead of as one HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp8", action="store_true", help="Llama prefill projections as W8A8 e4m3 GEMMs (BASELINE configs[4] extension; not the bf16 headline)")
+    ap.add_argument("--fp8-wgrad", action="store_true", help="--mode train --fp8: the decoder layers' weight-gradient GEMMs on the e4m3 path too")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="train: one optimisation step of run_vla_training per bench step (BASELINE configs[2] / [3])")
     ap.add_argument("--stage", default="vla-full-train", choices=["vla-full-train", "vla-train", "lora"],
@@ -138,6 +139,35 @@ def per_kernel_profile(eng) -> dict:
         a["flops"] += op.flops
         a["bytes"] += op.bytes
     return agg
+
+
+def cpu_baseline_whole(dims, ids0, pv0, gpu_ids0) -> dict:
+    """The WHOLE CPU oracle (oracle/restate.py: both towers, projector, 32-layer prefill, 6 cached decode steps, greedy) for
+    ONE sequence of the workload — sequence 0 of rank 0's batch, on the same synthetic checkpoint the GPU ran — timed once
+    on this host's cores (used when the host has >= 64 cores and 64 GB free: the checkpoint is held as fp32, 30 GB;
+    otherwise the per-block extrapolation below). Also reports whether its 7 ids equal the GPU's."""
+    from bridgelang_amd import weights as W
+    from oracle import pick_threads, restate as R, synth as S
+    pick_threads()
+    torch.set_flush_denormal(True)
+    t0 = time.perf_counter()
+    sd = S.synth_state_dict(W.tensor_specs(dims, "init"), seed=0)
+    for k in list(sd):                      # "model load": keep the (bf16-valued) weights as fp32 tensors, so the timed region
+        sd[k] = sd[k].float()               # is arithmetic, not 7 bf16→fp32 conversions of the checkpoint (30 GB of host RAM)
+    t_ckpt = time.perf_counter() - t0
+    model = R.OracleModel.from_dims(sd, dims)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        gen, _ = model.generate(ids0, pv0, n_new=7, last_row_only=True)
+    per_seq = time.perf_counter() - t0
+    same = gen[0].tolist() == list(gpu_ids0)
+    return {"value": 1.0 / per_seq, "unit": "action-seqs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": (f"oracle/restate.py, the whole {dims.name} path for ONE sequence (sequence 0 of the batch: both towers, "
+                       f"projector, Llama prefill S={ids0.shape[1] + dims.n_patches}, 6 cached decode steps, greedy) timed once: "
+                       f"{per_seq:.1f} s (+ {t_ckpt:.0f} s to generate the synthetic checkpoint on the host and hold it as fp32, not timed); "
+                       f"oracle ids {gen[0].tolist()} {'==' if same else '!='} GPU ids (random-init logits are nearly flat: a "
+                       f"difference is a near tie, tests/test_cfg_7b_golden_gpu.py)"),
+            "ids_equal_gpu": same}
 
 
 def cpu_baseline(dims, B: int, L: int) -> dict:
@@ -264,7 +294,7 @@ def train_line(args, rank: int, world: int, dev) -> dict:
     ts = TrainStep(w, args.stage, B, L, max_grad_norm=1.0 if lora is None else float("inf"),
                    weight_decay=0.0 if lora is None else 0.01, lora=lora, world=world, rank=rank,
                    reduce_dtype=torch.float32 if args.reduce == "fp32" else torch.bfloat16, recompute=args.recompute,
-                   shard_params=args.shard_params, fp8=args.fp8)
+                   shard_params=args.shard_params, fp8=args.fp8, fp8_wgrad=getattr(args, "fp8_wgrad", False))
     g = torch.Generator().manual_seed(100 + rank)         # each rank draws its own stream (base_strategy.py:259-266)
     ids = torch.randint(3, 31000, (B, L), generator=g)
     ids[:, 0] = 1
@@ -336,7 +366,8 @@ def train_line(args, rank: int, world: int, dev) -> dict:
                        "batch_per_gpu": B, "global_batch": B * world, "seq_len": ts.S, "stage": args.stage,
                        "parallelism": (f"dp{world} sharded-optimizer ({'full-shard: decoder-layer parameters sharded' if args.shard_params else 'shard-grad-op'})"
                                        if world > 1 else "single GPU"),
-                       "hip_graph": graph, "recompute_activations": bool(args.recompute), "shard_params": bool(args.shard_params), "fp8_fwd_dgrad": bool(args.fp8)},
+                       "hip_graph": graph, "recompute_activations": bool(args.recompute), "shard_params": bool(args.shard_params), "fp8_fwd_dgrad": bool(args.fp8),
+                       "fp8_wgrad": bool(getattr(args, "fp8_wgrad", False))},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "kernel": "tiled MFMA GEMM family per call: bl_gemm_bf16 (forward, dgrad), bl_gemm_tn_bf16 (wgrad)" + (", bl_gemm_fp8 (e4m3 forward / dgrad; priced against the bf16 peak)" if args.fp8 else ""),
@@ -367,7 +398,7 @@ def train_legs(args, dev) -> dict:
     for key, stage, batch in (("train_cfg2_n1", "vla-full-train", 32), ("train_cfg3_lora_n1", "lora", 16)):
         a = copy.copy(args)
         a.mode, a.stage, a.batch, a.steps, a.warmup = "train", stage, batch, 3, 1
-        a.recompute = a.shard_params = a.fp8 = False
+        a.recompute = a.shard_params = a.fp8 = a.fp8_wgrad = False
         a.reduce = "fp32"
         gc.collect()
         torch.cuda.empty_cache()
@@ -456,6 +487,7 @@ def main() -> None:
         elapsed = timed(pipe.step, args.steps)   # every step submits one batch and completes the one submitted 6 steps earlier
         ids_pipe = pipe.step().clone().cpu()
     ids_out = eng.gen_ids.t().cpu()
+    ids_cpu0, pv_cpu0 = ids[:1].cpu(), pv[:1].cpu()
     if args.pipeline >= 7 and rank == 0:
         pipe_agree = float((ids_pipe == ids_out).all(dim=1).float().mean())
 
@@ -523,7 +555,11 @@ def main() -> None:
             del eng, w, prof
             line["end_to_end"].update(train_legs(args, dev))
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would wait at the barrier)
-            line["cpu_baseline"] = cpu_baseline(dims, args.batch, args.prompt_len)
+            big_host = (os.cpu_count() or 1) >= 64 and os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") > (64 << 30)
+            if big_host and args.model == "openvla-7b":
+                line["cpu_baseline"] = cpu_baseline_whole(dims, ids_cpu0, pv_cpu0, ids_out[0].tolist())
+            else:
+                line["cpu_baseline"] = cpu_baseline(dims, args.batch, args.prompt_len)
         print(json.dumps(line), flush=True)
     if distributed:
         torch.distributed.barrier()

@@ -296,6 +296,7 @@ __global__ void resample_pass_kernel(const uint8_t* src, uint8_t* dst, int B, in
 // restatement vla/eval_preprocess.py::crop_and_resize_bilinear — results are bit-identical to it.
 __global__ void crop_resize_bilinear_kernel(const uint8_t* src, uint8_t* dst, int B, int H, int W, int oh, int ow,
                                             float y_base, float y_step, float x_base, float x_step) {
+#pragma clang fp contract(off)   // HIP's __fmul_rn / __fadd_rn are plain operators: without this hipcc fuses them into v_fma
   const long total = (long)B * oh * ow;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     const int j = (int)(t % ow), i = (int)((t / ow) % oh);

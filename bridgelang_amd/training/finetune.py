@@ -68,10 +68,8 @@ def finetune(vlm, dataloader: Iterable[Dict[str, Any]], action_tokenizer, cfg: F
         m = vla_action_metrics(logits, batch["labels"], action_tokenizer, num_patches=num_patches)
         recent["loss"].append(float(loss)); recent["acc"].append(m["action_accuracy"]); recent["l1"].append(m["l1_loss"])
         accum = cfg.grad_accumulation_steps
-        if accum > 1:                                  # normalized_loss = loss / accum (finetune.py:256-262)
-            if world > 1:
-                raise NotImplementedError("gradient accumulation with the sharded optimizer")
-            engine.accumulate(1.0 / accum)
+        if accum > 1:                                  # normalized_loss = loss / accum (finetune.py:256-262); under the sharded
+            engine.accumulate(1.0 / accum)             # optimizer every micro-batch is reduced and this rank's slices accumulate
         if (batch_idx + 1) % accum == 0:               # finetune.py:307-310
             if accum > 1:
                 engine.use_accumulated()

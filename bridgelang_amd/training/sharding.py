@@ -132,18 +132,24 @@ class ShardComm:
         """SUM-reduce bucket b of the flat gradient over ranks; afterwards this rank's slice holds the reduced values
         (other slices are unspecified). Callers pre-divide the loss gradient by `world`, so SUM is the DDP average.
         reduce_dtype=bf16 sends a bf16 copy (`scratch`, same numel as the bucket) — fsdp.py:139-147's reduce_dtype."""
+        if self.active:
+            self.reduce_scatter_bucket(grad[b.offset:b.offset + b.numel], b, scratch)
+
+    def reduce_scatter_bucket(self, full: torch.Tensor, b: Bucket, scratch: Optional[torch.Tensor] = None) -> None:
+        """The same on a bucket-local tensor `full` ([b.numel] fp32: a range of the flat gradient, or the transient slot a
+        parameter-sharded layer's weight gradients were written to): afterwards full[rank·n : (rank+1)·n] holds the sum."""
         if not self.active:
             return
-        lo, hi = self.layout.shard_range(b)
-        full = grad[b.offset:b.offset + b.numel]
-        if self.reduce_dtype != grad.dtype:
+        n = self.layout.shard_numel(b)
+        lo = self.layout.rank * n
+        if self.reduce_dtype != full.dtype:
             send = scratch[:b.numel]
             _cast(full, send)
-            mine = send[lo - b.offset:hi - b.offset]
+            mine = send[lo:lo + n]
             self._rs(mine, send)
-            _cast(mine, grad[lo:hi])
+            _cast(mine, full[lo:lo + n])
         else:
-            self._rs(grad[lo:hi], full)
+            self._rs(full[lo:lo + n], full)
 
     def _rs(self, out: torch.Tensor, full: torch.Tensor) -> None:
         if self._native_rs:

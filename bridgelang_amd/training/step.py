@@ -92,7 +92,7 @@ class ParamStore:
 
     def __init__(self, w: VLAWeights, stage: str, world: int = 1, rank: int = 0,
                  extra: Optional[List[Tuple[str, torch.Tensor, bool, str]]] = None, only: Optional[Sequence[str]] = None,
-                 shard_params: bool = False):
+                 shard_params: bool = False, defer_grads: bool = False):
         """`extra`: additional trainable bf16 tensors outside the model's own table — (name, flat live tensor, decayed,
         bucket key), e.g. LoRA adapters. `only`: restrict the stage's trainable set to these HF names (whole fused groups;
         diagnostics / tests: optimizer state for a handful of tensors instead of the model). `shard_params`: the
@@ -153,20 +153,29 @@ class ParamStore:
         self.total = lay.total
         self.n_params = sum(u.numel for u in self.units)
         dev = w.embed.device
-        self.grad = torch.zeros(max(lay.total, 8), dtype=torch.float32, device=dev)
-        # bf16 staging copy of the updated parameters: every bucket but the parameter-sharded ones (a contiguous range
-        # [lo, hi) of the flat space, cut out of the staging buffer's addressing)
+        # Parameter-sharded buckets (FSDP FULL_SHARD units = the decoder layers) occupy a contiguous range [lo, hi) of the
+        # flat space that is CUT OUT of the addressing of the replicated buffers — the bf16 staging copy of the updated
+        # parameters and the flat fp32 gradient: for those buckets a rank keeps only its 1/world slice of the parameters
+        # (`own`, bf16) and of the reduced gradient (`gshard`, fp32); the full gradient of ONE layer exists transiently in
+        # one of two slots (`gslots`) between that layer's weight-gradient GEMMs and its reduce-scatter, as FSDP frees a
+        # unit's full gradient after reduce-scatter (fsdp.py:160-168).
         self.shard_params = shard_params
         sh = [b for b in lay.buckets if shard_params and b.key.startswith("llm.layer")]
         self.sharded_keys = {b.key for b in sh}
         self._cut = (sh[0].offset, sh[-1].offset + sh[-1].numel) if sh else (lay.total, lay.total)
         assert sum(b.numel for b in sh) == self._cut[1] - self._cut[0], "parameter-sharded buckets must be contiguous"
-        self.stage_bf16 = torch.zeros(max(lay.total - (self._cut[1] - self._cut[0]), 8), dtype=torch.bfloat16, device=dev)
+        self._n_rep = n_rep = lay.total - (self._cut[1] - self._cut[0])
+        self.stage_bf16 = torch.zeros(max(n_rep, 8), dtype=torch.bfloat16, device=dev)
         self.own_off, n_own = {}, 0
         for b in sh:
             self.own_off[b.key] = n_own
             n_own += lay.shard_numel(b)
+        self._n_own, self._slot_numel = n_own, max((b.numel for b in sh), default=0)
         self.own = torch.zeros(max(n_own, 8), dtype=torch.bfloat16, device=dev) if sh else None
+        self.grad = self.gshard = None
+        self.gslots: List[torch.Tensor] = []
+        if not defer_grads:                 # TrainStep defers: it first gives the model's own decoder-layer allocation back
+            self.alloc_grads()
         f = lambda: torch.zeros(max(lay.local_total, 8), dtype=torch.float32, device=dev)
         self.master, self.m, self.v = f(), f(), f()
         for bi, b in enumerate(lay.buckets):                    # masters ← this rank's slice of the live bf16 weights
@@ -189,38 +198,78 @@ class ParamStore:
         self.norm_coef = torch.zeros(2, dtype=torch.float32, device=dev)     # [total norm, clip coefficient]
         self.step_count = 0
 
+    def alloc_grads(self) -> None:
+        """The fp32 gradient buffers: flat for the replicated buckets; this rank's slices + two transient layer slots for
+        the parameter-sharded ones."""
+        if self.grad is not None:
+            return
+        dev = self.w.embed.device
+        self.grad = torch.zeros(max(self._n_rep, 8), dtype=torch.float32, device=dev)
+        if self.sharded_keys:
+            self.gshard = torch.zeros(max(self._n_own, 8), dtype=torch.float32, device=dev)
+            self.gslots = [torch.zeros(self._slot_numel, dtype=torch.float32, device=dev) for _ in range(2)]
+
     # ---- views ----
+    def _replicated(self, buf: torch.Tensor, offset: int, numel: int) -> torch.Tensor:
+        """View of flat range [offset, offset + numel) in a buffer that skips the parameter-sharded range."""
+        lo, hi = self._cut
+        assert offset + numel <= lo or offset >= hi, "parameter-sharded buckets have no replicated copy"
+        o = offset if offset < lo else offset - (hi - lo)
+        return buf[o:o + numel]
+
     def stage_view(self, offset: int, numel: int) -> torch.Tensor:
         """bf16 staging view of flat range [offset, offset + numel) (never inside the parameter-sharded range)."""
-        lo, hi = self._cut
-        assert offset + numel <= lo or offset >= hi, "no staging copy exists for parameter-sharded buckets"
-        o = offset if offset < lo else offset - (hi - lo)
-        return self.stage_bf16[o:o + numel]
+        return self._replicated(self.stage_bf16, offset, numel)
+
+    def grad_range(self, offset: int, numel: int) -> torch.Tensor:
+        """fp32 gradient of flat range [offset, offset + numel) of the replicated buckets."""
+        return self._replicated(self.grad, offset, numel)
 
     def own_slice(self, b) -> torch.Tensor:
         """This rank's bf16 slice of a parameter-sharded bucket."""
         o = self.own_off[b.key]
         return self.own[o:o + self.layout.shard_numel(b)]
 
+    def grad_slot(self, b) -> torch.Tensor:
+        """The transient full-size fp32 gradient of parameter-sharded bucket b (decoder layer l uses slot l % 2)."""
+        return self.gslots[int(b.key[len("llm.layer"):]) % 2][:b.numel]
+
+    def reduced_grad(self, b) -> torch.Tensor:
+        """This rank's slice of bucket b's gradient once reduced: what the norm and AdamW read."""
+        if b.key in self.sharded_keys:
+            o = self.own_off[b.key]
+            return self.gshard[o:o + self.layout.shard_numel(b)]
+        lo, hi = self.layout.shard_range(b)
+        return self.grad_range(lo, hi - lo)
+
+    def _unit_grad(self, u: Unit) -> torch.Tensor:
+        b = self.layout.buckets[u.bucket]
+        if b.key in self.sharded_keys:
+            return self.grad_slot(b)[u.offset - b.offset:u.offset - b.offset + u.numel]
+        return self.grad_range(u.offset, u.numel)
+
     def grad_view(self, name_or_unit) -> torch.Tensor:
-        """fp32 gradient of a unit: [n, k] for a group, flat for a plain tensor."""
+        """fp32 gradient of a unit: [n, k] for a group, flat for a plain tensor (for a parameter-sharded decoder layer:
+        the transient slot the layer's weight-gradient GEMMs write — valid until the slot's next layer overwrites it)."""
         u = name_or_unit if isinstance(name_or_unit, Unit) else self.by_name[name_or_unit]
-        sl = self.grad[u.offset:u.offset + u.numel]
+        sl = self._unit_grad(u)
         return sl.view(u.group.n, u.group.k) if u.group is not None else sl
 
-    def _named(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+    def _named(self, flat: Optional[torch.Tensor], name: str, unit_slice: Optional[torch.Tensor] = None) -> torch.Tensor:
         u = self.by_name[name]
+        sl = unit_slice if unit_slice is not None else flat[u.offset:u.offset + u.numel]
         if name not in self.w.placements:                       # extra unit: flat
-            return flat[u.offset:u.offset + u.numel]
+            return sl
         pl = self.w.placements[name]
         shape = self.w._specs()[name].shape
         if u.group is None:
-            return flat[u.offset:u.offset + u.numel].view(shape)
-        return _block_view(flat[u.offset:u.offset + u.numel], pl).reshape(shape)
+            return sl.view(shape)
+        return _block_view(sl, pl).reshape(shape)
 
     def named_grad(self, name: str) -> torch.Tensor:
-        """Local (un-reduced) gradient under its HF name / shape (a copy for grouped tensors)."""
-        return self._named(self.grad, name)
+        """Local (un-reduced) gradient under its HF name / shape (a copy for grouped tensors). For a parameter-sharded
+        decoder layer this reads the transient slot: meaningful only for the two layers whose backward ran last."""
+        return self._named(None, name, self._unit_grad(self.by_name[name]))
 
     def full_master(self, comm: Optional[ShardComm] = None) -> torch.Tensor:
         """All fp32 masters in the flat layout (gathered over ranks when sharded) — checkpoints and tests."""
@@ -257,7 +306,8 @@ class TrainStep:
     def __init__(self, weights: VLAWeights, stage: str, batch: int, prompt_len: int, *, max_grad_norm: float = 1.0,
                  weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8, store: Optional[ParamStore] = None,
                  world: int = 1, rank: int = 0, group=None, reduce_dtype: torch.dtype = torch.float32, lora=None,
-                 force_comm: bool = False, recompute: bool = False, shard_params: bool = False, fp8: bool = False):
+                 force_comm: bool = False, recompute: bool = False, shard_params: bool = False, fp8: bool = False,
+                 fp8_wgrad: bool = False):
         """`lora`: a training.lora.LoraAdapters → stage "lora": the base model is frozen and only the adapters train.
         `recompute`: keep only each decoder layer's input and replay its forward inside the backward pass.
         `shard_params`: FSDP FULL_SHARD for the decoder layers (fsdp.py:84-87) — every rank keeps 1/world of each layer's
@@ -268,14 +318,21 @@ class TrainStep:
         run W8A8 on the e4m3 MFMA path (BASELINE configs[4]) — activations / output gradients quantised per token row,
         weights per output channel (forward) and per input channel (the transposed dgrad copy), fp32 accumulation, bf16
         results; weight gradients stay bf16 x bf16 (TN GEMM), masters and AdamW fp32. No reference counterpart: agreement
-        with the bf16 step is to quantisation noise (tests/test_train_step_gpu.py states the bound)."""
+        with the bf16 step is to quantisation noise (tests/test_train_step_gpu.py states the bound).
+        `fp8_wgrad` (with `fp8`): the decoder layers' WEIGHT-gradient GEMMs run on the e4m3 MFMA path too, so all three GEMM
+        families of those layers are fp8: dW[n, k] = Σ_t dy[t, n]·x[t, k] contracts over tokens, so dy and x are transposed
+        to token-contiguous rows and quantised per ROW of the transposed matrix — one scale per output channel n of dy and
+        per input channel k of x, i.e. along the non-contracted dimensions, where the scales factor out of the sum exactly —
+        and dW = s_dy[n]·s_x[k]·(dyT8 · xT8ᵀ) accumulates in fp32 straight into the flat gradient buffer."""
         if (lora is not None) != (stage == "lora"):
             raise ValueError("stage 'lora' and the `lora` adapters go together")
         if (recompute or shard_params or fp8) and lora is not None:
             raise ValueError("activation recomputation / parameter sharding / fp8 GEMMs are planned for the full-parameter stages only")
         if fp8 and (weights.dims.llm_dim % 128 or weights.dims.llm_inter % 128):
             raise ValueError("fp8 GEMMs need llm_dim and llm_inter to be multiples of 128")
-        self.fp8 = fp8
+        if fp8_wgrad and not fp8:
+            raise ValueError("fp8_wgrad extends fp8=True (e4m3 forward / dgrad) to the weight-gradient GEMMs")
+        self.fp8, self.fp8_wgrad = fp8, fp8_wgrad
         self.recompute, self.shard_params = recompute, shard_params
         self.lora = lora
         self.train_vision = STAGES[stage][0] or lora is not None      # towers need their training-form forward
@@ -287,7 +344,7 @@ class TrainStep:
         self.max_grad_norm, self.weight_decay, self.betas, self.eps = max_grad_norm, weight_decay, betas, eps
         if store is None:
             store = ParamStore(weights, stage, world, rank, extra=lora.plain_units() if lora is not None else None,
-                               shard_params=shard_params)
+                               shard_params=shard_params, defer_grads=True)
         self.store = store
         assert self.store.stage == stage and self.store.shard_params == shard_params
         shard_params = self.shard_params = shard_params and bool(self.store.sharded_keys)      # frozen LLM: nothing to shard
@@ -302,6 +359,7 @@ class TrainStep:
         self._materialized = False
         if shard_params:                       # first: the model's layer allocation is given back before anything else is reserved
             self._setup_param_shards()
+        st.alloc_grads()
         B, S, D, I, V, NL = batch, self.S, d.llm_dim, d.llm_inter, d.vocab, d.llm_layers
         Tn = B * S
         self.T, self.Tp = Tn, (Tn + 63) // 64 * 64
@@ -407,6 +465,16 @@ class TrainStep:
         self._q8 = {D: u8(Tn, D), I: u8(Tn, I)}                          # quantised GEMM inputs (one linear at a time)
         self._q8_dy = u8(Tn, max(3 * D, 2 * I))                          # quantised output gradients
         self._sx, self._sdy = (torch.zeros(Tn, dtype=torch.float32, device=dev) for _ in range(2))
+        if self.fp8_wgrad:                     # token-contiguous (transposed) operands of the e4m3 weight-gradient GEMM
+            Tq = (Tn + 127) // 128 * 128       # its contraction length: tokens, padded with zero columns to the MFMA's K = 128
+            nmx = max(3 * D, 2 * I)
+            self._Tq = Tq
+            self._wg_tA = torch.zeros(nmx * Tq, dtype=torch.bfloat16, device=dev)      # dyᵀ [N, Tq] bf16
+            self._wg_tB = torch.zeros(I * Tq, dtype=torch.bfloat16, device=dev)        # xᵀ  [K, Tq] bf16
+            self._wg_qA, self._wg_qB = u8(nmx * Tq), u8(I * Tq)                        # their e4m3 codes
+            self._wg_pB = torch.zeros(I * Tq // 2, dtype=torch.bfloat16, device=dev)   # xᵀ codes in the fragment-major packing
+            self._wg_sA = torch.zeros(nmx, dtype=torch.float32, device=dev)
+            self._wg_sB = torch.zeros(I, dtype=torch.float32, device=dev)
         self._fp8_scratch()
         if self.shard_params:                  # sharded layers are quantised in their gather (slots carry the e4m3 copies)
             return
@@ -469,6 +537,7 @@ class TrainStep:
                 if not self.fp8:
                     slot[key + "T"] = torch.zeros(p.shape[1] * 2, p.shape[0] // 2, 64, 8, dtype=torch.bfloat16, device=dev)
             slot["ready"], slot["free"] = torch.cuda.Event(), torch.cuda.Event()
+            slot["grads_flushed"] = torch.cuda.Event()     # the gradient slot of the same parity has been reduced and kept
             self._slots.append(slot)
         self._slot_key = {slot[k].data_ptr(): k for slot in self._slots for k in self._LAYER_KEYS}
         if self.fp8:
@@ -526,6 +595,32 @@ class TrainStep:
     def _release_ops(self, l: int) -> Op:
         return ops.glue("release_layer_params", lambda: self._slots[l % 2]["free"].record(torch.cuda.current_stream()), ())
 
+    def _await_grad_slot_ops(self, l: int) -> Op:
+        """Before layer l's weight-gradient GEMMs write gradient slot l % 2: the flush of the layer that used it last
+        (l + 2) must be over."""
+        return ops.glue("await_grad_slot", lambda: torch.cuda.current_stream().wait_event(self._slots[l % 2]["grads_flushed"]), ())
+
+    def _flush_grads_ops(self, l: int) -> Op:
+        """After layer l's last weight-gradient GEMM: on the communication stream, reduce-scatter the layer's full fp32
+        gradient (slot l % 2) over the ranks — in place, this rank's slice of the slot receives the sum (bf16 wire copy
+        when reduce_dtype says so) — and keep that slice in the persistent sharded gradient; the slot is then free for
+        layer l - 2. The full gradient of a decoder layer therefore lives for two layers' worth of backward, as under
+        FSDP (fsdp.py:160-168), instead of the whole step."""
+        def fn():
+            st, lay, side = self.store, self.store.layout, self._comm_stream
+            b = self._layer_bucket(l)
+            slot = st.grad_slot(b)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                scratch = self._rs_scratch[:b.numel] if self._rs_scratch is not None else None
+                self.comm.reduce_scatter_bucket(slot, b, scratch)
+                n = lay.shard_numel(b)
+                T.copy_f32(slot[lay.rank * n:(lay.rank + 1) * n], st.reduced_grad(b))
+                self._slots[l % 2]["grads_flushed"].record(side)
+        return ops.glue("flush_layer_grads", fn, ())
+
     def _unit_of(self, packed: torch.Tensor) -> Optional[Unit]:
         if self.shard_params and packed.data_ptr() in self._slot_key:
             assert self._cur_layer >= 0, "slot weights are only addressed while a decoder layer is being planned"
@@ -568,12 +663,22 @@ class TrainStep:
     def _dgrad(self, dy: torch.Tensor, packed: torch.Tensor, out: torch.Tensor, epilogue: int = EPI_NONE, **kw) -> Op:
         return self._g(dy, self.wT(packed), out, epilogue, **kw)
 
-    def _wgrad_into(self, dy: torch.Tensor, x: torch.Tensor, gview: torch.Tensor) -> List[Op]:
+    def _wgrad_into(self, dy: torch.Tensor, x: torch.Tensor, gview: torch.Tensor, fp8: bool = False) -> List[Op]:
         """gview[N, K] (fp32) = dyᵀ[N, T] · x[T, K]: the TN GEMM reads dy and x where they lie (transposing LDS reads);
-        BL_WGRAD_NT=1 keeps the round-1 form — the NT GEMM over token-padded transposed copies — as the A/B reference."""
+        BL_WGRAD_NT=1 keeps the round-1 form — the NT GEMM over token-padded transposed copies — as the A/B reference.
+        fp8=True: the e4m3 form (TrainStep(fp8_wgrad=True)) — transpose, quantise per channel, NT GEMM on bl_gemm_fp8."""
         Tn, N = dy.shape
         K = x.shape[1]
         assert tuple(gview.shape) == (N, K), (dy.shape, x.shape, gview.shape)
+        if fp8:
+            Tq = self._Tq
+            tA, tB = self._wg_tA[:N * Tq].view(N, Tq), self._wg_tB[:K * Tq].view(K, Tq)
+            qA, qB = self._wg_qA[:N * Tq].view(N, Tq), self._wg_qB[:K * Tq].view(K, Tq)
+            pB = self._wg_pB[:K * Tq // 2].view(K // 16, Tq // 64, 64, 8)
+            sA, sB = self._wg_sA[:N], self._wg_sB[:K]
+            return [T.transpose_pad(dy, tA, Tq, run=False), ops.quantize_rows_fp8(tA, qA, sA, run=False)[2],
+                    T.transpose_pad(x, tB, Tq, run=False), ops.quantize_rows_fp8(tB, qB, sB, run=False)[2],
+                    T.pack(qB.view(torch.bfloat16), pB, run=False), ops.gemm_fp8(qA, sA, pB, sB, gview, EPI_F32, run=False)]
         if not WGRAD_NT and N % 8 == 0 and K % 8 == 0:
             return [T.gemm_tn(dy, x, gview, workspace=self.ws, run=False)]
         Tp = (Tn + 63) // 64 * 64
@@ -590,7 +695,10 @@ class TrainStep:
     def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, packed: torch.Tensor) -> List[Op]:
         """Weight gradient of a base linear; [] when the weight is frozen."""
         u = self._unit_of(packed)
-        return [] if u is None else self._wgrad_into(dy, x, self.store.grad_view(u))
+        if u is None:
+            return []
+        fp8 = self.fp8_wgrad and packed.data_ptr() in self._w8 and dy.shape[1] % 16 == 0 and x.shape[1] % 16 == 0
+        return self._wgrad_into(dy, x, self.store.grad_view(u), fp8=fp8)
 
     def _build_extended_weights(self) -> None:
         """LoRA: K-concatenated packed weights [W | s·B] (forward) and [Wᵀ | Aᵀ] (dgrad) per adapted linear. The frozen
@@ -746,6 +854,7 @@ class TrainStep:
                 plan.append(self._await_ops(l))
                 if l - 1 >= stop_layer:
                     plan.append(self._gather_ops(l - 1, backward=True))
+                plan.append(self._await_grad_slot_ops(l))
             if self.recompute:         # incl. the top layer: the plan stays idempotent (graph capture runs it twice)
                 plan += self._layer_forward(l, with_down=False)
             plan += lb(dx, self.act[l], lw.down_w, self.dact)
@@ -763,6 +872,7 @@ class TrainStep:
             plan += lb(dq, self.h1[l], lw.qkv_w, self.dh)
             if self.shard_params:
                 plan.append(self._release_ops(l))
+                plan.append(self._flush_grads_ops(l))      # reduce-scatter + keep this rank's slice; frees the gradient slot
             self._ready.append((len(plan), f"llm.layer{l:02d}"))
             plan.append(T.rmsnorm_backward(self.x[l], lw.ln1, self.dh, dx, self._gvec(f"{b}.input_layernorm.weight", D),
                                            self.norm_ws, d.rms_eps, dres=dx2, run=False))
@@ -1001,6 +1111,8 @@ class TrainStep:
         st, lay = self.store, self.store.layout
         if not self.comm.active:
             self._replay("bwd", self.backward_ops, graph)
+            if self.shard_params:                                  # the per-layer gradient flushes ran on the side stream
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
             return
         self.mean_cnt[1].mul_(self.world)                          # dlogits / world: the SUM over ranks is the DDP mean
         main = torch.cuda.current_stream()
@@ -1008,16 +1120,14 @@ class TrainStep:
         done, reduced = 0, set()
 
         def reduce(b):
+            reduced.add(b.key)
+            if b.key in st.sharded_keys:                           # reduced by the flush step inside the plan
+                return
             ev = torch.cuda.Event()
             ev.record(main)
             self._comm_stream.wait_event(ev)
             with torch.cuda.stream(self._comm_stream):
-                if b.key in st.sharded_keys:
-                    scratch = self._rs_scratch[:b.numel] if self._rs_scratch is not None else None
-                else:
-                    scratch = st.stage_view(b.offset, b.numel)
-                self.comm.reduce_scatter_grads(st.grad, b, scratch)
-            reduced.add(b.key)
+                self.comm.reduce_scatter_bucket(st.grad_range(b.offset, b.numel), b, st.stage_view(b.offset, b.numel))
         for upto, key in self._ready:
             ops.run_all(self.backward_ops[done:upto])
             done = upto
@@ -1033,14 +1143,20 @@ class TrainStep:
     def accumulate(self, scale: float = 1.0) -> None:
         """Gradient accumulation: add scale × (this micro-batch's gradients) to the accumulator (allocated on first use).
         `use_accumulated()` then makes the accumulated sum the gradient the optimizer step sees."""
-        st = self.store
+        st, lay = self.store, self.store.layout
         if getattr(st, "grad_acc", None) is None:
-            st.grad_acc = torch.zeros_like(st.grad)
-        T.axpy(st.grad_acc, st.grad, scale)
+            st.grad_acc = torch.zeros(max(lay.local_total, 8), dtype=torch.float32, device=self.device)
+        # after backward() every bucket's gradient is reduced over the ranks and this rank's slice is in place: the
+        # accumulator holds slices only (1/world of the model), so accumulation works unchanged under the sharded optimizer
+        for b in lay.buckets:
+            o, n = lay.local_offset(b), lay.shard_numel(b)
+            T.axpy(st.grad_acc[o:o + n], st.reduced_grad(b), scale)
 
     def use_accumulated(self) -> None:
-        st = self.store
-        st.grad.copy_(st.grad_acc)          # D2D copy (plumbing); the accumulator is cleared for the next window
+        st, lay = self.store, self.store.layout
+        for b in lay.buckets:               # D2D copies (plumbing); the accumulator is cleared for the next window
+            o, n = lay.local_offset(b), lay.shard_numel(b)
+            T.copy_f32(st.grad_acc[o:o + n], st.reduced_grad(b))
         T.fill_zero(st.grad_acc)
 
     def clip_grad_norm(self) -> torch.Tensor:
@@ -1049,8 +1165,7 @@ class TrainStep:
         all-reduced. Returns the device scalar total norm."""
         st, lay, nb = self.store, self.store.layout, self.store.blocks_per_bucket
         for i, b in enumerate(lay.buckets):
-            lo, hi = lay.shard_range(b)
-            T.sumsq_partial(st.grad[lo:hi], st.partial[i * nb:(i + 1) * nb])
+            T.sumsq_partial(st.reduced_grad(b), st.partial[i * nb:(i + 1) * nb])
         self.comm.all_reduce_sum(st.partial)
         T.clip_coef(st.partial, self.max_grad_norm, st.norm_coef)
         return st.norm_coef[0]
@@ -1066,7 +1181,7 @@ class TrainStep:
             lo, hi = lay.shard_range(b)
             sl = slice(lay.local_offset(b), lay.local_offset(b) + hi - lo)
             sharded = b.key in st.sharded_keys                     # parameter-sharded: the rank's bf16 slice IS the parameter
-            T.adamw(st.master[sl], st.m[sl], st.v[sl], st.grad[lo:hi], st.step_count, lr, betas=self.betas, eps=self.eps,
+            T.adamw(st.master[sl], st.m[sl], st.v[sl], st.reduced_grad(b), st.step_count, lr, betas=self.betas, eps=self.eps,
                     weight_decay=self.weight_decay if b.decay else 0.0, norm_coef=st.norm_coef,
                     p_bf16=st.own_slice(b) if sharded else st.stage_view(lo, hi - lo))
             if self.comm.active and not sharded:                   # gather bucket i while AdamW runs on bucket i+1

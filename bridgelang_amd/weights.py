@@ -120,7 +120,11 @@ class TensorSpec:
 
 
 RECIPES = ("init", "decisive", "margin")
-MARGIN_BRANCH_SCALE = 1.0 / 16.0     # "margin": residual branches this much smaller again than "decisive"'s
+MARGIN_BRANCH_SCALE = 1.0 / 16.0     # "margin": residual branches this much smaller again than "decisive"'s …
+MARGIN_LIVE_SCALE = 2.0              # … except the last decoder layer's attention output projection: this x the init std
+MARGIN_LIVE_MLP_SCALE = 0.5          # … and its MLP down projection: this x the init std
+MARGIN_BOOSTED_ROWS = 32             # "margin" boosts the lm_head rows of the 32 highest action bins only (fewer competitors:
+                                     # the top-2 gap of the logits is a larger share of the logit scale)
 
 
 def tensor_seed(name: str, seed: int) -> int:
@@ -196,14 +200,18 @@ def tensor_specs(d: VLADims, recipe: str = "init") -> List[TensorSpec]:
     std (they then carry the stream), and — as an overlay, synthetic_overlays() — the lm_head rows of the 256 action
     tokens are 6x larger, so greedy decoding lands in the action vocabulary as a fine-tuned OpenVLA does.
 
-    recipe="margin" is "decisive" with every residual branch a further 16x smaller (MARGIN_BRANCH_SCALE). Between two
-    correct fp32 summation orders the relative difference of the residual stream grows by about 0.0024 x (branch / stream
-    ratio) per residual add (each re-rounding of the stream to bf16 turns the branch's small difference into rare
-    whole-ulp flips; DESIGN.md §4 "noise floor"), so on this checkpoint the logit noise falls to about one bf16 ulp of
-    the logit scale — small enough that sequences whose oracle top-2 gap is >= 3x that noise at all 7 steps exist and
-    can be selected (tests/golden/make_margin_b16.py): the fixture on which the WHOLE [16, 7] id matrix must be
-    bit-exact. The price: the stream is dominated by the token / patch embeddings, so ids depend on the inputs only
-    weakly; input sensitivity is what the "init" / "decisive" fixtures and the per-op full-size tests cover."""
+    recipe="margin" is "decisive" with every residual branch a further 16x smaller (MARGIN_BRANCH_SCALE) EXCEPT the
+    attention branch of the LAST decoder layer, whose o_proj is 2x the init scale. Between two correct fp32 summation
+    orders the relative difference of the residual stream grows by about 0.0024 x (branch / stream ratio) x (relative
+    difference of the branch input) per residual add — each re-rounding of the stream to bf16 turns the branch's small
+    difference into rare whole-ulp flips (DESIGN.md §4 "noise floor") — so 63 contractive adds keep the stream's
+    difference at a fraction of a percent, and ONE large branch at the very end, fed by that quiet stream, adds the
+    input-dependent content (the last position attends over the 256 image-patch rows and the prompt) without adding
+    noise. On this checkpoint the logit noise is about one bf16 ulp of the logit scale, small enough that sequences
+    whose oracle top-2 gap is >= 3x that noise at all 7 steps exist and can be selected
+    (tests/golden/make_margin_b16.py): the fixture on which the WHOLE [16, 7] id matrix must be bit-exact. Layers 0..30
+    contribute little to the result here; their sensitivity is what the "init" / "decisive" fixtures and the per-op
+    full-size tests cover."""
     if recipe not in RECIPES:
         raise ValueError(f"unknown synthetic recipe {recipe!r}")
     out = list(_tower_specs(d.dino)) + list(_tower_specs(d.siglip))
@@ -228,7 +236,12 @@ def tensor_specs(d: VLADims, recipe: str = "init") -> List[TensorSpec]:
         extra = MARGIN_BRANCH_SCALE if recipe == "margin" else 1.0
         depth = {d.dino.prefix: d.dino.n_run, d.siglip.prefix: d.siglip.n_run, "language_model": d.llm_layers}
 
+        live = {f"language_model.model.layers.{d.llm_layers - 1}.self_attn.o_proj.weight": MARGIN_LIVE_SCALE,
+                f"language_model.model.layers.{d.llm_layers - 1}.mlp.down_proj.weight": MARGIN_LIVE_MLP_SCALE}
+
         def adjust(sp: TensorSpec) -> TensorSpec:
+            if recipe == "margin" and sp.name in live:
+                return TensorSpec(sp.name, sp.shape, sp.mean, sp.std * live[sp.name])
             if sp.name.endswith((".attn.proj.weight", ".mlp.fc2.weight", ".o_proj.weight", ".down_proj.weight")):
                 n = next(v for k, v in depth.items() if sp.name.startswith(k))
                 return TensorSpec(sp.name, sp.shape, sp.mean, sp.std * extra / (2.0 * n) ** 0.5)
@@ -248,8 +261,9 @@ def synthetic_overlays(d: VLADims, recipe: str = "init") -> List[TensorSpec]:
     tensors of the state dict). "decisive" / "margin": the lm_head rows of the action tokens."""
     if recipe not in ("decisive", "margin") or d.vocab < TOKENIZER_VOCAB:
         return []
-    return [TensorSpec("language_model.lm_head.weight#action_rows", (N_ACTION_TOKENS, d.llm_dim), 0.0, 0.12,
-                       base="language_model.lm_head.weight", row0=TOKENIZER_VOCAB - N_ACTION_TOKENS)]
+    n = N_ACTION_TOKENS if recipe == "decisive" else MARGIN_BOOSTED_ROWS
+    return [TensorSpec("language_model.lm_head.weight#action_rows", (n, d.llm_dim), 0.0, 0.12,
+                       base="language_model.lm_head.weight", row0=TOKENIZER_VOCAB - n)]
 
 
 # ---- packed device layout --------------------------------------------------------------------------------------

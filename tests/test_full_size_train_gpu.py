@@ -13,7 +13,12 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _free_gpu_memory():
-    """These tests allocate tens of GB: drop whatever earlier modules left in reference cycles / the caching allocator."""
+    """These tests allocate tens to hundreds of GB: drop whatever earlier modules left in reference cycles / the caching
+    allocator, and the synthetic checkpoints test_cfg_7b_golden_gpu keeps for its own parametrisations (15 GB each)."""
+    import sys
+    cached = getattr(sys.modules.get("test_cfg_7b_golden_gpu"), "_W", None)
+    if cached:
+        cached.clear()
     gc.collect()
     torch.cuda.empty_cache()
     yield
@@ -154,3 +159,82 @@ def test_cfg5_form_at_13b_widths(dev):
     assert all(l == l and n == n and n > 0 for l, n in out[True][0])                 # finite
     assert out[False][0] == out[True][0]
     assert torch.equal(out[False][1], out[True][1])
+
+
+def _dummy_batches(B, L, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        ids = torch.randint(3, 31000, (B, L), generator=g)
+        ids[:, 0] = 1
+        ids[:, -8:-1] = torch.randint(31744, 32000, (B, 7), generator=g)
+        ids[:, -1] = 2
+        labels = torch.full((B, L), -100)
+        labels[:, -8:] = ids[:, -8:]
+        out.append((ids, labels, torch.randn(B, 6, 224, 224, generator=g).to(torch.bfloat16)))
+    return out
+
+
+def test_cfg5_full_depth_13b_full_shard_fp8_recompute(dev):
+    """BASELINE configs[4] in its OWN form at FULL depth: the 40-layer Llama-2-13B VLA (13.8 B parameters), full fine-tune,
+    FSDP full-shard parameter gathers + e4m3 GEMMs + activation recomputation, one GPU's share of the step (the gather is
+    a copy at world size 1). No oracle reaches this size; the step is checked through properties: every loss and
+    gradient norm finite, the loss FALLS over three optimizer steps on one batch (forward, backward, clip, AdamW and the
+    per-layer gather / re-quantise cycle all act on the same parameters), the model's decoder layers are sharded out during
+    training and come back bit-consistent with the fp32 masters afterwards."""
+    from bridgelang_amd.training.step import TrainStep
+    from bridgelang_amd.weights import allocate, prism_13b_dims
+    dims = prism_13b_dims()
+    assert dims.llm_layers == 40 and dims.llm_dim == 5120
+    B, L = 4, 40
+    (ids, labels, pv), = _dummy_batches(B, L, 1, seed=7)
+    w = allocate(dims, dev).fill_synthetic(seed=0)
+    ts = TrainStep(w, "vla-full-train", B, L, max_grad_norm=1.0, weight_decay=0.0, fp8=True, shard_params=True, recompute=True)
+    assert not w.layers_resident and ts.store.n_params > 13.5e9
+    ts.set_batch(ids, None, pv, labels)
+    log = []
+    for _ in range(3):
+        loss, norm = ts.step(2e-5)
+        log.append((loss.item(), norm.item()))
+    torch.cuda.synchronize()
+    gib = torch.cuda.max_memory_allocated() / 2 ** 30
+    print(f"\n13B full-shard + fp8 + recompute, 40 layers, B = {B}: (loss, grad norm) per step {[(round(l, 4), round(n, 2)) for l, n in log]}, "
+          f"{ts.store.n_params / 1e9:.2f} B trainable parameters, peak {gib:.0f} GiB")
+    assert all(l == l and n == n and 0 < n < float("inf") for l, n in log)
+    assert log[2][0] < log[1][0] < log[0][0], "the loss must fall on a repeated batch"
+    ts.materialize_params()
+    assert w.layers_resident
+    lw = w.layers[39]
+    from bridgelang_amd import ops
+    got = ops.unpack_weight(lw.o_w).float()
+    u = ts._layer_units[(39, "o_w")]                     # world 1: the rank's master slice is the whole flat space
+    want = ts.store.master[u.offset:u.offset + u.numel].view(u.group.n, u.group.k).to(torch.bfloat16).float()
+    assert torch.equal(got, want), "materialised layer weights must be the bf16 rounding of the fp32 masters"
+    del ts, w
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def test_cfg5_fp8_gradient_norm_close_to_bf16_on_a_13b_prefix(dev):
+    """The stated fp8 bound at 13B widths: on a 4-layer prefix of the 13B decoder the first step's loss agrees with the
+    bf16 step within 2 % and the global gradient norm within 5 % (same weights, same batch; e4m3 forward / dgrad GEMMs vs
+    bf16 — quantisation noise, not a bit-exact claim)."""
+    import dataclasses
+    from bridgelang_amd.training.step import TrainStep
+    from bridgelang_amd.weights import allocate, prism_13b_dims
+    dims = dataclasses.replace(prism_13b_dims(), llm_layers=4)
+    B, L = 4, 40
+    (ids, labels, pv), = _dummy_batches(B, L, 1, seed=9)
+    res = {}
+    for fp8 in (False, True):
+        w = allocate(dims, dev).fill_synthetic(seed=0)
+        ts = TrainStep(w, "vla-train", B, L, max_grad_norm=1.0, fp8=fp8)
+        ts.set_batch(ids, None, pv, labels)
+        loss, norm = ts.step(1e-5)
+        res[fp8] = (loss.item(), norm.item())
+        del ts, w
+        gc.collect()
+        torch.cuda.empty_cache()
+    (l0, n0), (l1, n1) = res[False], res[True]
+    print(f"\n13B-width 4-layer prefix: bf16 loss {l0:.4f} norm {n0:.3f} | fp8 loss {l1:.4f} norm {n1:.3f}")
+    assert abs(l1 - l0) <= 0.02 * abs(l0) and abs(n1 - n0) <= 0.05 * n0

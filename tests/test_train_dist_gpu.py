@@ -50,11 +50,41 @@ assert not w2.layers_resident and ts2.store.own.numel() * world <= sum(b.numel f
 assert out2 == out, (out, out2)
 sd2 = ts2.store.master_state_dict(ts2.comm)
 assert all(torch.equal(sd[k], sd2[k]) for k in sd)
+# ... and so is the GRADIENT of every decoder layer: the flat fp32 gradient no longer covers the layer buckets, each rank
+# keeps 1/world of their reduced gradient, the full gradient of a layer lives in one of two transient slots
+layer_total = sum(b.numel for b in ts2.store.layout.buckets if b.key.startswith("llm.layer"))
+assert ts2.store.grad.numel() <= ts.store.grad.numel() - layer_total + 8
+assert ts2.store.gshard.numel() * world <= layer_total + 8 and len(ts2.store.gslots) == 2
+per_rank = lambda t: (t.store.grad.numel() + (t.store.gshard.numel() + sum(g.numel() for g in t.store.gslots) if t.store.gshard is not None else 0)) * 4
+print(f"rank {rank}: fp32 gradient bytes per rank: shard-grad-op {per_rank(ts)}, full-shard {per_rank(ts2)} "
+      f"(persistent {(ts2.store.grad.numel() + ts2.store.gshard.numel()) * 4} + 2 slots)", flush=True)
 ts2.materialize_params()
 live2 = w2.state_dict()
 assert all(torch.equal(live[k], live2[k].cpu()) for k in live)
+# gradient accumulation under the sharded optimizer (vla-scripts/finetune.py:264,315 grad_accumulation_steps): two
+# micro-batches per optimizer step, each reduced over the ranks, accumulated as this rank's slices
+def run_accum(w, shard_params):
+    ts = TrainStep(w, "vla-train", B // world, L, max_grad_norm=1.0, weight_decay=0.1, world=world, rank=rank, reduce_dtype=rd,
+                   shard_params=shard_params)
+    out = []
+    for step in range(2):
+        for micro in range(2):
+            ids, mask, labels, pv = make_batch(dims, B, L, seed=40 + 2 * step + micro, ragged=False)
+            sl = slice(rank * B // world, (rank + 1) * B // world)
+            ts.set_batch(ids[sl], mask[sl], pv[sl], labels[sl])
+            ts.forward(); ts.backward(); ts.accumulate(0.5)
+        ts.use_accumulated()
+        norm = ts.clip_grad_norm().item()
+        ts.optimizer_step(1e-3)
+        out.append(norm)
+    return ts, out
+ta, norms_a = run_accum(allocate(dims, dev).fill_synthetic(seed=3), False)
+tb, norms_b = run_accum(allocate(dims, dev).fill_synthetic(seed=3), True)
+assert norms_a == norms_b, (norms_a, norms_b)
+ma, mb = ta.store.master_state_dict(ta.comm), tb.store.master_state_dict(tb.comm)
+assert all(torch.equal(ma[k], mb[k]) for k in ma)
 if rank == 0:
-    torch.save({"log": out, "master": {k: v.cpu() for k, v in sd.items()}, "live": live}, os.environ["BL_OUT"])
+    torch.save({"log": out, "master": {k: v.cpu() for k, v in sd.items()}, "live": live, "accum_norms": norms_a}, os.environ["BL_OUT"])
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -97,6 +127,21 @@ def test_two_rank_sharded_step_matches_single_process(dev, tmp_path, reduce):
         assert c > (0.90 if reduce == "bf16" else 0.98), (k, c)
         assert torch.equal(got["live"][k].float(), got["master"][k].to(torch.bfloat16).float()), k
     print("worst update cosine", worst)
+    # gradient accumulation: two micro-batches per step, single process on the whole micro-batches vs the two sharded ranks
+    w3 = allocate(dims, dev).fill_synthetic(seed=3)
+    ts3 = TrainStep(w3, "vla-train", B, L, max_grad_norm=1.0, weight_decay=0.1)
+    norms = []
+    for step in range(2):
+        for micro in range(2):
+            ids, mask, labels, pv = make_batch(dims, B, L, seed=40 + 2 * step + micro, ragged=False)
+            ts3.set_batch(ids, mask, pv, labels)
+            ts3.forward(); ts3.backward(); ts3.accumulate(0.5)
+        ts3.use_accumulated()
+        norms.append(ts3.clip_grad_norm().item())
+        ts3.optimizer_step(1e-3)
+    print("accumulated grad norms: single", norms, "two sharded ranks", got["accum_norms"])
+    assert all(abs(a - b) <= tol * a for a, b in zip(norms, got["accum_norms"]))
+    print("".join(o for o in outs if "gradient bytes" in o)[-600:])
 
 
 _W0 = {}
