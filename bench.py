@@ -308,7 +308,8 @@ def train_line(args, rank: int, world: int, dev) -> dict:
     pv = torch.cat([(img - m) / sd, (img - 0.5) / 0.5], dim=1).to(torch.bfloat16)
     ts.set_batch(ids, None, pv, labels)                   # batch resident in HBM before the timed region
     lr = 2e-5 if lora is None else 5e-4
-    graph = not args.no_graph and world == 1              # sharded runs keep the backward eager (per-bucket collectives)
+    graph = not args.no_graph      # at world > 1 TrainStep keeps the backward (per-bucket collectives) and the parameter-sharded
+                                   # plans eager by itself; forward, vision forward and the re-pack plan still replay as HIP graphs
     losses = []
     for _ in range(max(args.warmup, 1)):
         loss, _ = ts.step(lr, graph=graph)
@@ -501,7 +502,8 @@ def main() -> None:
         skinny = prof.get("bl_gemm_skinny_bf16")
         kern_ms = sum(a["ms"] for a in prof.values())
         traffic = None      # HBM bytes per GEMM call from the committed PMC passes (bench.py cannot run rocprofv3 itself)
-        pmc = ROOT / "profiles" / "pmc_r02_final" / "gemm_traffic.json"
+        pmc = next((q for q in (ROOT / "profiles" / d / "gemm_traffic.json" for d in ("pmc_r03", "pmc_r02_final")) if q.exists()),
+                   ROOT / "profiles" / "pmc_r03" / "gemm_traffic.json")
         if pmc.exists() and args.model == "openvla-7b" and args.batch == 16 and args.prompt_len == 32 and not args.fp8:
             traffic = round(json.loads(pmc.read_text())["avg_hbm_bytes_per_call_llama_layer"])
         # algorithmic work per sequence: the SURVEY figure for the BASELINE model, the plan's own GEMM + attention FLOPs otherwise
@@ -523,7 +525,7 @@ def main() -> None:
                        "replicas": world, "hip_graph": not args.no_graph, "pipeline_depth": args.pipeline},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "traffic_note": "avg HBM+Infinity-Cache bytes per bl_gemm_bf16 call over the 4 Llama prefill GEMMs, separate --pmc passes (profiles/pmc_r02_final/gemm_traffic.json)",
+                         "traffic_note": f"avg HBM+Infinity-Cache bytes per bl_gemm_bf16 call over the 4 Llama prefill GEMMs, separate --pmc passes (profiles/{pmc.parent.name}/gemm_traffic.json)",
                          "kernel": ("gemm256s_fp8_kernel (per bl_gemm_fp8 call)" if args.fp8 else
                                     "tiled MFMA GEMM family: gemm256s_kernel / gemm288s_kernel + gemm_tail_kernel (per bl_gemm_bf16 call)"), "launches_per_step": gemm["launches"],
                          "avg_launch_us": round(gemm["ms"] * 1e3 / gemm["launches"], 2),

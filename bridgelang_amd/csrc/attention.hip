@@ -313,6 +313,30 @@ __global__ __launch_bounds__(512) void attn_seq_kernel(AttnArgs p, int s_pad) {
     }
   }
   __syncthreads();
+  // key visibility (key < Skv and not hidden by the key-padding mask) of this lane's keys kt·16 + lg·4 + {0..3} of every
+  // key tile, one bit each: read from global memory ONCE per workgroup instead of inside every query tile's score loop
+  uint32_t mbits[(NKT * 4 + 31) / 32] = {};            // bit kt·4 + rr
+  {
+    const bool words = mrow != nullptr && ((((uintptr_t)mrow) & 3) == 0);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int k0 = kt * 16 + lg * 4;
+      uint32_t w = 0;                                   // 4 bits: visibility of keys k0 .. k0 + 3
+      if (mrow == nullptr) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) w |= (k0 + rr < p.Skv ? 1u : 0u) << rr;
+      } else if (words && k0 + 3 < p.Skv) {
+        const uint32_t raw = *(const uint32_t*)(mrow + k0);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) w |= (((raw >> (8 * rr)) & 0xffu) != 0 ? 1u : 0u) << rr;
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          if (k0 + rr < p.Skv && mrow[k0 + rr] != 0) w |= 1u << rr;
+      }
+      mbits[(kt * 4) >> 5] |= w << ((kt * 4) & 31);
+    }
+  }
 
   // query tiles, heaviest (causal) first: with few (batch, head) pairs (batch-1 serving: 32 workgroups on 256 CUs) gridDim.y
   // workgroups share a head — workgroup y takes tiles y, y + gridDim.y, … and stages K / V itself (L2-resident)
@@ -351,43 +375,71 @@ __global__ __launch_bounds__(512) void attn_seq_kernel(AttnArgs p, int s_pad) {
         }
       }
     }
-    // ---- S^T = K · Q^T for every needed key tile ----
+    // ---- S^T = K · Q^T for every needed key tile, two key tiles (32 keys) per step. The K fragments of step g + 1 are
+    //      read from LDS BEFORE the MFMAs of step g are issued (two register buffers), so a fragment's LDS latency passes
+    //      under the previous step's matrix work instead of in front of every MFMA (the single-buffer form the compiler
+    //      chose at 249 VGPRs waited lgkmcnt(0) before each of the 144 MFMAs of a query tile: 6 x the MFMA time). ----
     float sc[NKT][4];
     float mx = -INFINITY;
+    bf16x8_t kb[2][2 * KS];
+    auto load_k = [&](int g, bf16x8_t* dst) {
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      if (kt * 16 < kv_hi) {
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8_t kf = *(const bf16x8_t*)(k_lds + (kt * 16 + l15) * ROWB + (((lg + 4 * ks) ^ (l15 & MASK)) << 4));
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);
-        }
+        for (int ks = 0; ks < KS; ++ks)
+          dst[t * KS + ks] = *(const bf16x8_t*)(k_lds + ((2 * g + t) * 16 + l15) * ROWB + (((lg + 4 * ks) ^ (l15 & MASK)) << 4));
+    };
+    load_k(0, kb[0]);
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int key = kt * 16 + lg * 4 + rr;
-          bool vis = key < p.Skv;
-          if (CAUSAL) vis = vis && (key <= qrow + off);
-          if (mrow) vis = vis && (key < p.Skv ? mrow[key] != 0 : false);
-          sc[kt][rr] = vis ? acc[rr] * p.scale_log2e : -INFINITY;
-          mx = fmaxf(mx, sc[kt][rr]);
+    for (int g = 0; g < NKT / 2; ++g) {
+      if (g * 32 < kv_hi) {
+        if (g + 1 < NKT / 2 && (g + 1) * 32 < kv_hi) load_k(g + 1, kb[(g + 1) & 1]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int kt = 2 * g + t;
+          f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb[g & 1][t * KS + ks], qf[ks], acc, 0, 0, 0);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int key = kt * 16 + lg * 4 + rr;
+            bool vis = ((mbits[(kt * 4 + rr) >> 5] >> ((kt * 4 + rr) & 31)) & 1u) != 0;   // in range and not masked
+            if (CAUSAL) vis = vis && (key <= qrow + off);
+            sc[kt][rr] = vis ? acc[rr] * p.scale_log2e : -INFINITY;
+            mx = fmaxf(mx, sc[kt][rr]);
+          }
         }
       } else {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) sc[kt][rr] = -INFINITY;
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) sc[2 * g + t][rr] = -INFINITY;
       }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_use = (mx == -INFINITY) ? 0.f : mx;
-    // ---- P = exp2(S - m); O^T += V^T · P^T, 32 keys (two key tiles) per MFMA k-step ----
+    // ---- P = exp2(S - m); O^T += V^T · P^T, 32 keys (two key tiles) per MFMA k-step; V fragments double-buffered like K ----
     f32x4_t o[DT];
 #pragma unroll
     for (int i = 0; i < DT; ++i) o[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     float l = 0.f;
+    s16x4_t vb[2][2 * DT];
+    auto load_v = [&](int s2, s16x4_t* dst) {
+      const int key = 32 * s2 + 4 * lg + (l15 >> 2);            // +16 for the second read: same (key & MASK)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int pr = dt ^ ((key >> VSH) & VPM);                // swizzled 32-byte pair (same for key + 16)
+        const char* vp = v_lds + key * ROWB + (((pr << 1) | ((l15 & 3) >> 1)) << 4) + (l15 & 1) * 8;
+        dst[2 * dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)vp);
+        dst[2 * dt + 1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp + 16 * ROWB));
+      }
+    };
+    load_v(0, vb[0]);
 #pragma unroll
     for (int s2 = 0; s2 < NKT / 2; ++s2) {
       if (s2 * 32 < kv_hi) {
+        if (s2 + 1 < NKT / 2 && (s2 + 1) * 32 < kv_hi) load_v(s2 + 1, vb[(s2 + 1) & 1]);
         float e[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -398,14 +450,9 @@ __global__ __launch_bounds__(512) void attn_seq_kernel(AttnArgs p, int s_pad) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) t[j] = pack2bf(e[2 * j], e[2 * j + 1]);
         const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, t);
-        const int key = 32 * s2 + 4 * lg + (l15 >> 2);          // +16 for the second read: same (key & MASK)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const int pr = dt ^ ((key >> VSH) & VPM);                  // swizzled 32-byte pair (same for key + 16)
-          const char* vp = v_lds + key * ROWB + (((pr << 1) | ((l15 & 3) >> 1)) << 4) + (l15 & 1) * 8;
-          const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)vp);
-          const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp + 16 * ROWB));
-          const u32x2_t w0 = __builtin_bit_cast(u32x2_t, v0), w1 = __builtin_bit_cast(u32x2_t, v1);
+          const u32x2_t w0 = __builtin_bit_cast(u32x2_t, vb[s2 & 1][2 * dt]), w1 = __builtin_bit_cast(u32x2_t, vb[s2 & 1][2 * dt + 1]);
           const u32x4_t vv = {w0[0], w0[1], w1[0], w1[1]};
           o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pf, o[dt], 0, 0, 0);
         }

@@ -107,6 +107,20 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(BwdArgs p, int s_pad) 
   stage_two<HD, ROWB>(k_lds, v_lds, p.k + (long)b * p.k_bs + (long)h * p.k_hs, p.k_rs,
                       p.v + (long)b * p.v_bs + (long)h * p.v_hs, p.v_rs, s_pad, p.Skv, tid);
   __syncthreads();
+  // key visibility (key < Skv and not hidden by the key-padding mask) of this lane's keys kt·16 + lg·4 + {0..3}, one bit each
+  // (bit kt·4 + rr of an 80-bit set): read ONCE per workgroup — the score loop used to load one mask byte per score from
+  // global memory and wait for it (8 exposed L2 round trips per 32-key step, the dominant cost of this kernel in training)
+  uint32_t mb0 = 0, mb1 = 0, mb2 = 0;
+#pragma unroll
+  for (int kt = 0; kt < 20; ++kt) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int key = kt * 16 + lg * 4 + rr;
+      if (key < p.Skv && (mrow == nullptr || mrow[key] != 0)) w |= 1u << rr;
+    }
+    if (kt < 8) mb0 |= w << (kt * 4); else if (kt < 16) mb1 |= w << ((kt - 8) * 4); else mb2 |= w << ((kt - 16) * 4);
+  }
 
   const int nqt = (p.Sq + 15) >> 4;
   for (int r = 0; r * 8 < nqt; ++r) {
@@ -147,6 +161,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(BwdArgs p, int s_pad) 
     for (int i = 0; i < DT; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     for (int s2 = 0; s2 * 32 < kv_hi; ++s2) {
       float e[8];
+      const uint32_t vis8 = ((s2 < 4 ? mb0 : (s2 < 8 ? mb1 : mb2)) >> ((s2 & 3) * 8)) & 0xffu;   // bits half·4 + rr of this step
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int kt = 2 * s2 + half;
@@ -159,9 +174,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(BwdArgs p, int s_pad) 
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int key = kt * 16 + lg * 4 + rr;
-          bool vis = key < p.Skv;
+          bool vis = ((vis8 >> (half * 4 + rr)) & 1u) != 0;
           if (CAUSAL) vis = vis && (key <= qrow + off);
-          if (mrow) vis = vis && (key < p.Skv ? mrow[key] != 0 : false);
           const float pr = vis ? __builtin_amdgcn_exp2f(as[rr] * p.scale_log2e - lse_q) : 0.f;
           e[half * 4 + rr] = pr * (ap[rr] - dsum);
         }
@@ -237,8 +251,24 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(BwdArgs p, int s_pad)
     for (int i = 0; i < DT; ++i) dk[i] = dv[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     int q_lo = 0;
     if (CAUSAL) q_lo = max(0, k0 - off);                  // first query row that can see this key tile
+    // lse / delta of the query rows of step s2 are fetched one step ahead (their global-load latency used to sit in front
+    // of every step's softmax recomputation)
+    f32x4_t ln[2], dn[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      ln[half] = *(const f32x4_t*)(lse + (2 * (q_lo >> 5) + half) * 16 + lg * 4);
+      dn[half] = *(const f32x4_t*)(delta + (2 * (q_lo >> 5) + half) * 16 + lg * 4);
+    }
     for (int s2 = q_lo >> 5; s2 * 32 < p.Sq; ++s2) {
       float pe[8], de[8];
+      f32x4_t lc[2] = {ln[0], ln[1]}, dc[2] = {dn[0], dn[1]};
+      if ((s2 + 1) * 32 < p.Sq) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          ln[half] = *(const f32x4_t*)(lse + (2 * (s2 + 1) + half) * 16 + lg * 4);
+          dn[half] = *(const f32x4_t*)(delta + (2 * (s2 + 1) + half) * 16 + lg * 4);
+        }
+      }
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int qt = 2 * s2 + half;
@@ -248,8 +278,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(BwdArgs p, int s_pad)
           as = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<ROWB>(q_lds, qt * 16 + l15, lg + 4 * ks), kf[ks], as, 0, 0, 0);
           ap = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<ROWB>(g_lds, qt * 16 + l15, lg + 4 * ks), vf[ks], ap, 0, 0, 0);
         }
-        const f32x4_t l4 = *(const f32x4_t*)(lse + qt * 16 + lg * 4);      // stat rows are padded to 32
-        const f32x4_t d4 = *(const f32x4_t*)(delta + qt * 16 + lg * 4);
+        const f32x4_t l4 = lc[half], d4 = dc[half];                        // stat rows are padded to 32
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int q = qt * 16 + lg * 4 + rr;

@@ -296,18 +296,21 @@ __global__ void resample_pass_kernel(const uint8_t* src, uint8_t* dst, int B, in
 // restatement vla/eval_preprocess.py::crop_and_resize_bilinear — results are bit-identical to it.
 __global__ void crop_resize_bilinear_kernel(const uint8_t* src, uint8_t* dst, int B, int H, int W, int oh, int ow,
                                             float y_base, float y_step, float x_base, float x_step) {
-#pragma clang fp contract(off)   // HIP's __fmul_rn / __fadd_rn are plain operators: without this hipcc fuses them into v_fma
+  // Contraction OFF for this body, and plain operators only: HIP's __fmul_rn / __fadd_rn are header functions compiled under
+  // the default -ffp-contract=fast, so after inlining hipcc still fuses them into v_fma (seen in the ISA and as 1-LSB
+  // differences against the host restatement); operators written here carry this pragma's setting.
+#pragma clang fp contract(off)
   const long total = (long)B * oh * ow;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     const int j = (int)(t % ow), i = (int)((t / ow) % oh);
     const long b = t / ((long)ow * oh);
-    const float ys = __fadd_rn(y_base, __fmul_rn((float)i, y_step));
-    const float xs = __fadd_rn(x_base, __fmul_rn((float)j, x_step));
+    const float iy = (float)i * y_step, jx = (float)j * x_step;
+    const float ys = y_base + iy, xs = x_base + jx;
     uint8_t* q = dst + t * 3;
     if (!(ys >= 0.0f && ys <= (float)(H - 1) && xs >= 0.0f && xs <= (float)(W - 1))) { q[0] = q[1] = q[2] = 0; continue; }
     const float fy = floorf(ys), fx = floorf(xs);
-    const float wy = __fsub_rn(ys, fy), wx = __fsub_rn(xs, fx);
-    const float wy1 = __fsub_rn(1.0f, wy), wx1 = __fsub_rn(1.0f, wx);
+    const float wy = ys - fy, wx = xs - fx;
+    const float wy1 = 1.0f - wy, wx1 = 1.0f - wx;
     const int y0 = min(max((int)fy, 0), H - 1), y1 = min(max((int)fy + 1, 0), H - 1);
     const int x0 = min(max((int)fx, 0), W - 1), x1 = min(max((int)fx + 1, 0), W - 1);
     const uint8_t* r0 = src + (b * H + y0) * (long)W * 3;
@@ -315,14 +318,15 @@ __global__ void crop_resize_bilinear_kernel(const uint8_t* src, uint8_t* dst, in
     const float k = 1.0f / 255.0f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float p00 = __fmul_rn((float)r0[x0 * 3 + c], k), p01 = __fmul_rn((float)r0[x1 * 3 + c], k);
-      const float p10 = __fmul_rn((float)r1[x0 * 3 + c], k), p11 = __fmul_rn((float)r1[x1 * 3 + c], k);
-      const float top = __fadd_rn(__fmul_rn(p00, wx1), __fmul_rn(p01, wx));
-      const float bot = __fadd_rn(__fmul_rn(p10, wx1), __fmul_rn(p11, wx));
-      float v = __fadd_rn(__fmul_rn(top, wy1), __fmul_rn(bot, wy));
+      const float p00 = (float)r0[x0 * 3 + c] * k, p01 = (float)r0[x1 * 3 + c] * k;
+      const float p10 = (float)r1[x0 * 3 + c] * k, p11 = (float)r1[x1 * 3 + c] * k;
+      const float a0 = p00 * wx1, a1 = p01 * wx, b0 = p10 * wx1, b1 = p11 * wx;
+      const float top = a0 + a1, bot = b0 + b1;
+      const float t0 = top * wy1, t1 = bot * wy;
+      float v = t0 + t1;
       v = fminf(fmaxf(v, 0.0f), 1.0f);
-      v = fminf(fmaxf(__fmul_rn(v, 255.5f), 0.0f), 255.0f);
-      q[c] = (uint8_t)v;
+      const float s = v * 255.5f;
+      q[c] = (uint8_t)fminf(fmaxf(s, 0.0f), 255.0f);
     }
   }
 }

@@ -15,7 +15,7 @@ run_openvla_demo.py:21-28 — `register_auto_classes()` below; transformers >= 5
 weight arena on the GPU (no nn.Parameter copies of the 15 GB checkpoint); `.to()` / `.eval()` / `.device` / `.dtype`
 behave as on any HF model as long as the target is the GPU the weights already live on and bf16. The model owns no
 nn.Parameters (the weights are the arena), so autograd-based wrappers (PEFT, DDP) have nothing to hook: training goes
-through bridgelang_amd.training (scripts/finetune.py, scripts/train.py keep the reference scripts' flags).
+through bridgelang_amd.training (vla-scripts/finetune.py, vla-scripts/train.py keep the reference scripts' flags).
 
 Differences from the reference, all deliberate:
   * batched `predict_action` is supported (returns [B, 7]); batch 1 returns the reference's 1-D array.
@@ -148,7 +148,7 @@ class PrismaticForConditionalGeneration(PrismaticPreTrainedModel):
     def train(self, mode: bool = True):
         if mode:
             raise NotImplementedError("this class is the inference surface; training runs through bridgelang_amd.training "
-                                      "(scripts/train.py, scripts/finetune.py)")
+                                      "(vla-scripts/train.py, vla-scripts/finetune.py)")
         return super().train(False)
 
     # ---- weights ----

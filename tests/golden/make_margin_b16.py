@@ -7,7 +7,9 @@ checkpoint (tests/golden/make_noise_floor_7b.py → noise_floor_7b_margin_b1_s0_
 
 Candidate sequence s is BASELINE configs[1]'s input recipe drawn alone: make_inputs(1, 32, seed=s) (one uniform-uint8 224 px
 frame, BOS + 30 uniform ids + 29871). Candidates go through oracle/restate.py (CPU, openvla-7b, greedy 7 tokens) 16 at a
-time; a candidate is kept when min over its 7 steps of (top-1 − top-2) / max|logit| >= --min-gap. The first 16 kept
+time; a candidate is kept when min over its 7 steps of (top-1 − top-2) / max|logit| >= --min-gap and its 7 ids take at least
+--min-distinct different values (greedy chains that fall into a fixed point would pass the gap filter most easily and say
+least about the cached decode steps). The first 16 kept
 candidates, in seed order, are the fixture: their seeds, input ids, oracle ids, per-step gap and scale, and the oracle's
 top-32 logits per step (bf16 bit patterns). Data only; the selection is reproducible from the seeds.
 """
@@ -30,6 +32,8 @@ def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--recipe", default="margin")
     ap.add_argument("--min-gap", type=float, required=True)
+    ap.add_argument("--min-distinct", type=int, default=4, help="keep a candidate only if its 7 greedy ids take at least this "
+                    "many distinct values (a greedy chain that falls into a fixed point proves little about the decode steps)")
     ap.add_argument("--first-seed", type=int, default=1000)
     ap.add_argument("--max-candidates", type=int, default=320)
     ap.add_argument("--want", type=int, default=16)
@@ -67,7 +71,8 @@ def main() -> None:
         scale = logits.abs().amax(dim=-1)
         gap = (top2[..., 0] - top2[..., 1]) / scale
         tk = logits.topk(args.topk, dim=-1)
-        ok = gap.amin(dim=1) >= args.min_gap
+        distinct = torch.tensor([len(set(r)) for r in gen.tolist()])
+        ok = (gap.amin(dim=1) >= args.min_gap) & (distinct >= args.min_distinct)
         for j, s in enumerate(seeds):
             if ok[j] and len(kept) < args.want:
                 p = pv[j].float().double()
@@ -75,7 +80,7 @@ def main() -> None:
                              tk.values[j].to(torch.bfloat16).view(torch.int16).numpy(), tk.indices[j].numpy().astype(np.int32),
                              np.array([p.sum().item(), p.abs().sum().item()])))
         print(f"seeds {seeds[0]}..{seeds[-1]}: {time.time() - t0:.0f} s, min gap/scale per candidate "
-              f"{[round(v, 3) for v in gap.amin(dim=1).tolist()]} → kept {len(kept)}/{args.want} of {seen} "
+              f"{[round(v, 3) for v in gap.amin(dim=1).tolist()]}, distinct ids {distinct.tolist()} → kept {len(kept)}/{args.want} of {seen} "
               f"(distinct first ids in this group: {len(set(gen[:, 0].tolist()))}, distinct id rows: {len(set(map(tuple, gen.tolist())))})",
               flush=True)
     if len(kept) < args.want:
@@ -84,7 +89,7 @@ def main() -> None:
     col = lambda i: np.stack([k[i] for k in kept])
     np.savez_compressed(out, seq_seeds=np.array([k[0] for k in kept], dtype=np.int64), input_ids=col(1), ids=col(2).astype(np.int64),
                         top2_gap=col(3), logit_scale=col(4), topk_vals_bf16=col(5), topk_idx=col(6), pixel_checksum=col(7),
-                        min_gap=np.array(args.min_gap), candidates_seen=np.array(seen),
+                        min_gap=np.array(args.min_gap), min_distinct=np.array(args.min_distinct), candidates_seen=np.array(seen),
                         meta=np.array([args.want, args.prompt_len, args.first_seed, args.wseed]), recipe=np.array(args.recipe))
     g = col(3) / col(4)
     print(f"wrote {out}: seeds {[k[0] for k in kept]}, min gap/scale over all {g.size} (sequence, step) pairs {g.min():.4f}, "

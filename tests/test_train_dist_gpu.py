@@ -166,7 +166,7 @@ torch.cuda.set_device(dev)
 dist.init_process_group("nccl", device_id=dev)               # RCCL, one rank
 dims = tiny_dims()
 out = {}
-for mode in ("plain", "rccl-fp32", "rccl-bf16", "rccl-fullshard-fp32", "rccl-fullshard-bf16"):
+for mode in ("plain", "rccl-fp32", "rccl-fp32-graph", "rccl-bf16", "rccl-fullshard-fp32", "rccl-fullshard-bf16"):
     w = allocate(dims, dev).fill_synthetic(seed=3)
     kw = {} if mode == "plain" else dict(force_comm=True, reduce_dtype=torch.bfloat16 if mode.endswith("bf16") else torch.float32,
                                          shard_params="fullshard" in mode)
@@ -175,9 +175,11 @@ for mode in ("plain", "rccl-fp32", "rccl-bf16", "rccl-fullshard-fp32", "rccl-ful
     for step in range(2):
         ids, mask, labels, pv = make_batch(dims, 2, 20, seed=50 + step)
         ts.set_batch(ids, mask, pv, labels)
-        loss, norm = ts.step(1e-3)
+        loss, norm = ts.step(1e-3, graph=mode.endswith("graph"))
         log.append((loss.item(), norm.item()))
     out[mode] = (log, ts.store.full_master(ts.comm).cpu())
+# with collectives active, graph=True replays forward / re-pack as HIP graphs and keeps the backward eager: same bits
+assert out["rccl-fp32-graph"][0] == out["rccl-fp32"][0] and torch.equal(out["rccl-fp32-graph"][1], out["rccl-fp32"][1])
 assert out["plain"][0] == out["rccl-fp32"][0] and torch.equal(out["plain"][1], out["rccl-fp32"][1]), (out["plain"][0], out["rccl-fp32"][0])
 # FULL_SHARD (per-layer all_gather_into_tensor on RCCL, slots, packing on the comm stream) = replicated weights, bit for bit
 assert out["rccl-fullshard-fp32"][0] == out["rccl-fp32"][0] and torch.equal(out["rccl-fullshard-fp32"][1], out["rccl-fp32"][1])

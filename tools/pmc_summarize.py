@@ -16,6 +16,14 @@ for f in sorted(src.glob("*/p_counter_collection.csv")):
             k = k.replace("void ", "").split("(")[0]
             rows[r["Counter_Name"]].append((int(r["Dispatch_Id"]), k, int(r["Grid_Size"]), float(r["Counter_Value"]),
                                             int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+for f in sorted(src.glob("*/*/*_results.db")):            # rocprofv3's default output since ROCm 7: one rocpd database per pass
+    import sqlite3
+    cur = sqlite3.connect(f).cursor()
+    for d, k, g, c, v, t0, t1 in cur.execute("select dispatch_id, kernel_name, grid_size, counter_name, value, start, end "
+                                             "from counters_collection order by dispatch_id"):
+        if "bl_" not in k:
+            continue
+        rows[c].append((int(d), k.replace("void ", "").split("(")[0], int(g), float(v), int(t1) - int(t0)))
 for c, rs in rows.items():
     with open(dst / f"{c.lower()}_gemm_rows.csv", "w") as fh:
         fh.write("Dispatch_Id,Kernel,Grid_Size,Counter_Name,Counter_Value,DurationNs\n")
