@@ -200,18 +200,19 @@ def tensor_specs(d: VLADims, recipe: str = "init") -> List[TensorSpec]:
     std (they then carry the stream), and — as an overlay, synthetic_overlays() — the lm_head rows of the 256 action
     tokens are 6x larger, so greedy decoding lands in the action vocabulary as a fine-tuned OpenVLA does.
 
-    recipe="margin" is "decisive" with every residual branch a further 16x smaller (MARGIN_BRANCH_SCALE) EXCEPT the
-    attention branch of the LAST decoder layer, whose o_proj is 2x the init scale. Between two correct fp32 summation
-    orders the relative difference of the residual stream grows by about 0.0024 x (branch / stream ratio) x (relative
-    difference of the branch input) per residual add — each re-rounding of the stream to bf16 turns the branch's small
-    difference into rare whole-ulp flips (DESIGN.md §4 "noise floor") — so 63 contractive adds keep the stream's
-    difference at a fraction of a percent, and ONE large branch at the very end, fed by that quiet stream, adds the
-    input-dependent content (the last position attends over the 256 image-patch rows and the prompt) without adding
-    noise. On this checkpoint the logit noise is about one bf16 ulp of the logit scale, small enough that sequences
-    whose oracle top-2 gap is >= 3x that noise at all 7 steps exist and can be selected
-    (tests/golden/make_margin_b16.py): the fixture on which the WHOLE [16, 7] id matrix must be bit-exact. Layers 0..30
-    contribute little to the result here; their sensitivity is what the "init" / "decisive" fixtures and the per-op
-    full-size tests cover."""
+    recipe="margin" is "decisive" with every residual branch a further 16x smaller (MARGIN_BRANCH_SCALE) EXCEPT the two
+    branches of the LAST decoder layer, whose o_proj and down_proj keep the init scale (MARGIN_LIVE_SCALE /
+    MARGIN_LIVE_MLP_SCALE). Between two correct fp32 summation orders the relative difference of the residual stream
+    grows by about 0.0024 x (branch / stream ratio) x (relative difference of the branch input) per residual add — each
+    re-rounding of the stream to bf16 turns the branch's small difference into rare whole-ulp flips (DESIGN.md §4 "noise
+    floor") — so 62 contractive adds keep the stream's difference at a fraction of a percent, and two large branches at
+    the very end, fed by that quiet stream, add the input- and step-dependent content (the last position attends over the
+    256 image-patch rows and the prompt; the MLP hashes token and context) without much noise. On this checkpoint the
+    logit noise is 1.4 % of the logit scale (half of "decisive"'s) while the greedy ids still differ from sequence to
+    sequence and from step to step, and sequences whose oracle top-2 gap is >= 3x that noise at all 7 steps exist (about
+    one candidate in 35) and can be selected (tests/golden/make_margin_b16.py): the fixture on which the WHOLE [16, 7] id
+    matrix must be bit-exact. Layers 0..30 contribute little to the result here; their sensitivity is what the "init" /
+    "decisive" fixtures and the per-op full-size tests cover."""
     if recipe not in RECIPES:
         raise ValueError(f"unknown synthetic recipe {recipe!r}")
     out = list(_tower_specs(d.dino)) + list(_tower_specs(d.siglip))
