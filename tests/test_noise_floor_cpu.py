@@ -25,9 +25,9 @@ def _bits(a: np.ndarray) -> torch.Tensor:
     return torch.from_numpy(a.astype(np.int16)).view(torch.bfloat16).float()
 
 
-def load_noise_floor(recipe: str):
+def load_noise_floor(recipe: str, order: str = "tree8"):
     """→ (primary logits [1,7,V], alt logits [1,7,V], npz). Shared with the GPU test (bounds = 1.5 x measured floor)."""
-    z = np.load(GOLD / f"noise_floor_7b_{recipe}_b1_s0_tree8.npz")
+    z = np.load(GOLD / f"noise_floor_7b_{recipe}_b1_s0_{order}.npz")
     alt = _bits(z["logits_bf16"])
     prim_file = GOLD / f"cfg1_7b_{recipe}_b1_s0.npz"
     if prim_file.exists():
@@ -78,3 +78,17 @@ def test_margin_checkpoint_floor_is_below_the_others():
     f = {r: floor_of(r) for r in ("init", "decisive", "margin")}
     print(f"\nnoise floor (max |dlogit| / scale over 7 steps): {f}")
     assert f["margin"] < 0.6 * f["decisive"] < f["init"]
+
+
+def test_decisive_against_the_correctly_rounded_sums():
+    """A third order: every Linear accumulated in float64 and rounded once ("f64" — the correctly rounded sum). The
+    oracle's own BLAS order differs from it by as much as it differs from tree8 (and as the HIP path differs from the
+    oracle): none of the fp32 orders is privileged, the spread between them IS the floor."""
+    prim, alt, z = load_noise_floor("decisive", "f64")
+    assert str(z["order"]) == "f64"
+    d = ((alt - prim).abs().amax(-1) / prim.abs().amax(-1))[0]
+    biteq = (alt == prim).float().mean(-1)[0]
+    print(f"\noracle[blas] vs oracle[f64] on 'decisive': max |dlogit| / scale per step {[f'{v:.2e}' for v in d.tolist()]}, "
+          f"bit-equal {[f'{v:.3f}' for v in biteq.tolist()]}, ids equal {bool(np.array_equal(z['ids'], z['primary_ids']))}")
+    assert 1.5e-2 <= float(d.max()) <= 4.5e-2 and float(biteq.max()) <= 0.12
+    assert abs(float(d.max()) - floor_of("decisive")) <= 0.5 * floor_of("decisive")
