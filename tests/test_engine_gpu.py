@@ -143,3 +143,29 @@ def test_batch_equals_independent_calls(setup, dev):
         got = one.generate(ids[b:b + 1].to(dev), pv[b:b + 1].to(dev))
         assert torch.equal(got[0], full[b]), f"sequence {b}"
         assert torch.equal(one.logits[:, 0], full_logits[:, b]), f"sequence {b} logits"
+
+
+@pytest.mark.parametrize("seq", [2, 80, 150])
+def test_prompt_length_extremes_vs_oracle(setup, dev, seq):
+    """Edge prompt lengths: the shortest prompt predict_action can see (BOS + the 29871 it appends, S = 258) and prompts
+    beyond 64 tokens (S = 336 / 406 > 320: the prefill leaves the whole-sequence attention kernel for the chunked
+    online-softmax kernel + the stand-alone RoPE / KV-cache pass, decode attends over > 320 cached keys). Same bars as the
+    default-length test: prefill logits within the measured 2-layer bound, ids equal wherever the oracle is decisive."""
+    from bridgelang_amd.engine import OpenVLAEngine
+    dims, w, sd, oracle, *_ = setup
+    ids, pv = make_inputs(dims, batch=2, seq=seq, seed=100 + seq)
+    eng = OpenVLAEngine(w, 2, seq)
+    got = eng.generate(ids.to(dev), pv.to(dev)).cpu()
+    ref_ids, ref_logits = oracle.generate(ids, pv, n_new=7)
+    scale = ref_logits.abs().max().item()
+    err0 = (eng.logits[0].cpu() - ref_logits[:, 0]).abs().max().item() / scale
+    print(f"\nprompt length {seq} (S = {eng.S}): prefill logits err {err0:.3g}; ids {got.tolist()} vs oracle {ref_ids.tolist()}")
+    assert err0 <= LOGITS0_TOL
+    for b in range(2):
+        for t in range(7):
+            if got[b, t] != ref_ids[b, t]:
+                top2 = ref_logits[b, t].topk(2).values
+                assert (top2[0] - top2[1]).item() <= 2 * abs(top2[0].item()) * 2 ** -7, (seq, b, t)
+                break
+            err = (eng.logits[t, b].cpu() - ref_logits[b, t]).abs().max().item() / scale
+            assert err <= LOGITS_TOL, (seq, b, t, err)

@@ -314,6 +314,24 @@ def test_attention_prefill(dev, hd, H, Sq, causal):
     close_bf16(o, ref, f"attention hd={hd}", rtol=2 ** -5, atol_scale=2 ** -7, min_exact=0.98)
 
 
+@pytest.mark.parametrize("hd,H,Sq,causal", [(128, 2, 336, True), (128, 2, 406, True), (64, 2, 700, False), (72, 2, 333, False)])
+def test_attention_long_sequences_chunked_kernel(dev, hd, H, Sq, causal):
+    """Sequences beyond 320 positions (prompts longer than 64 tokens) take the chunked online-softmax kernel
+    (attn_fwd_kernel): same oracle, bf16-rounding tolerance — online rescaling changes the fp32 rounding of the
+    probabilities, so fewer outputs are bit-equal than with the exact two-pass kernel of the short path."""
+    from bridgelang_amd import ops
+    B, D = 2, H * hd
+    qkv = rand_bf16((B * Sq, 3 * D), hd + Sq)
+    Q = dv(qkv, dev)
+    o = torch.zeros(B * Sq, D, dtype=torch.bfloat16, device=dev)
+    st = (Sq * 3 * D, hd, 3 * D)
+    ops.attention(Q, Q[:, D:], Q[:, 2 * D:], o, B=B, H=H, Sq=Sq, Skv=Sq, head_dim=hd, q_strides=st, k_strides=st,
+                  v_strides=st, o_strides=(Sq * D, hd, D), causal=causal)
+    t = qkv.view(B, Sq, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = R.attention(P, t[0], t[1], t[2], hd ** -0.5, causal).permute(0, 2, 1, 3).reshape(B * Sq, D)
+    close_bf16(o, ref, f"chunked attention hd={hd} S={Sq}", rtol=2 ** -5, atol_scale=2 ** -7, min_exact=0.5)
+
+
 def test_attention_key_mask(dev):
     from bridgelang_amd import ops
     B, H, hd, S = 3, 2, 128, 100
