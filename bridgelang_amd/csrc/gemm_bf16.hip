@@ -1511,9 +1511,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   GemmArgs p = a;
   static const char* force = getenv("BL_GEMM_TILE");   // "128" / "256": benchmarking aid
   const int bm = (p.M + 255) / 256, bn = (p.N + 255) / 256, big_tiles = bm * bn;
-  // one (partial) round of big tiles beats 1.5+ rounds of the 128 kernel once ≥ ~3/4 of the CUs get a tile (ViT qkv at
-  // B = 16: 204 / 224 tiles, 45 → 39 µs)
-  bool big = big_tiles >= 200 && p.K >= 512;
+  // one (partial) round of big tiles beats 1.5+ rounds of the 128 kernel once about half of the CUs get a tile (ViT qkv at
+  // B = 16: 204 / 224 tiles, 45 → 39 µs; round 3, the narrow ViT layers at the training batch of 32 images — 132 / 160 tiles
+  // for M = 8352 / 8192, N = 1024 / 1152 — where the 128 kernel needs 528 / 576 > 512 workgroup slots: 104 → 82 µs at
+  // K = 4096, 35 → 30 µs at K = 1024)
+  bool big = big_tiles >= 128 && p.K >= 512;
   if (force) big = force[0] == '2';
   static const bool no_mid = getenv("BL_GEMM_NO_MID") != nullptr;      // A/B aid
   // M <= 320: the weight-streaming mid kernels; up to 640 rows (B = 2 prefill) the 160-row mid2 kernel still beats the
