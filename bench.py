@@ -354,6 +354,10 @@ def train_line(args, rank: int, world: int, dev) -> dict:
         achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
         model_flops = sum(op.flops for op in plan)
         ms = elapsed / args.steps * 1e3
+        train_traffic = None          # HBM bytes per forward GEMM call from the committed PMC passes (same M as this run only)
+        pmc = ROOT / "profiles" / "pmc_r03" / "gemm_traffic_train.json"
+        if pmc.exists() and args.model == "openvla-7b" and ts.T == 9472 and not args.fp8:
+            train_traffic = round(json.loads(pmc.read_text())["avg_hbm_bytes_per_call_llama_layer"])
         cfg_no = 4 if args.model == "prism-13b" else 3 if args.stage == "lora" else 2
         line = {
             "metric": f"samples/sec {dims.name} {args.stage} bf16", "value": round(world * B * args.steps / elapsed, 3), "unit": "samples/s",
@@ -370,7 +374,10 @@ def train_line(args, rank: int, world: int, dev) -> dict:
                        "hip_graph": graph, "recompute_activations": bool(args.recompute), "shard_params": bool(args.shard_params), "fp8_fwd_dgrad": bool(args.fp8),
                        "fp8_wgrad": bool(getattr(args, "fp8_wgrad", False))},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": train_traffic,
+                         "traffic_note": "avg HBM+Infinity-Cache bytes per forward bl_gemm_bf16 call over the 4 decoder-layer GEMM shapes at "
+                                         "M = 9472 token rows, separate --pmc passes (profiles/pmc_r03/gemm_traffic_train.json); dgrad / wgrad "
+                                         "launches of the family not counted" if train_traffic else None,
                          "kernel": "tiled MFMA GEMM family per call: bl_gemm_bf16 (forward, dgrad), bl_gemm_tn_bf16 (wgrad)" + (", bl_gemm_fp8 (e4m3 forward / dgrad; priced against the bf16 peak)" if args.fp8 else ""),
                          "launches_per_step": gemm["launches"], "avg_launch_us": round(gemm["ms"] * 1e3 / gemm["launches"], 2),
                          "algorithmic_gflop_per_launch": round(gemm["flops"] / gemm["launches"] / 1e9, 3)},

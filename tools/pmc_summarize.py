@@ -1,6 +1,6 @@
 """Condense the rocprofv3 --pmc passes of tools/pmc_gemm.py (one directory per pass, each with p_counter_collection.csv)
 into profiles/pmc_rNN/: the bl_* kernel rows as small CSVs + gemm_traffic.json + mfma_util.json.
-    python tools/pmc_summarize.py gpurun_out/pmc_r02 profiles/pmc_r02"""
+    python tools/pmc_summarize.py gpurun_out/pmc_r02 profiles/pmc_r02 [M [out-name.json]]   (M: rows of the driver run, default 4608)"""
 import csv, json, sys, collections
 from pathlib import Path
 src, dst = Path(sys.argv[1]), Path(sys.argv[2])
@@ -31,7 +31,8 @@ for c, rs in rows.items():
             if "gemm" in k:
                 fh.write(f"{d},{k},{g},{c},{v:.1f},{t}\n")
 # the driver launches qkv, o, gate_up, down three times each, in that order: group GEMM dispatches per call
-M = 16 * 288
+M = int(sys.argv[3]) if len(sys.argv) > 3 else 16 * 288
+OUT_NAME = sys.argv[4] if len(sys.argv) > 4 else "gemm_traffic.json"
 shapes = [("qkv N=12288 K=4096", 12288, 4096, 1.0), ("o N=4096 K=4096", 4096, 4096, 1.0),
           ("gate_up N=22016 K=4096", 22016, 4096, 0.5), ("down N=4096 K=11008", 4096, 11008, 1.0)]
 
@@ -56,7 +57,7 @@ traffic = {"how": ("separate passes on one MI355X: rocprofv3 --pmc FETCH_SIZE / 
                    "(bl_* rows beside this file). Units: KB → bytes. gfx950 correction: FETCH_SIZE x2 for wide coalesced reads "
                    "(guides/MI355X_MICROARCH.md, HBM); the counters include Infinity-Cache hits. WRITE_SIZE is uncalibrated for "
                    "8-byte-per-lane stores."),
-           "workload": "Llama-2-7B prefill GEMMs at B=16, S=288 (M=4608), one bl_gemm_bf16 call each, median of 3 calls",
+           "workload": f"Llama-2-7B GEMM shapes at M={M} rows, one bl_gemm_bf16 call each, median of 3 calls",
            "per_call": {}}
 fc, wc = per_call("FETCH_SIZE"), per_call("WRITE_SIZE")
 tot_h = tot_a = 0.0
@@ -72,7 +73,7 @@ for i, (name, N, K, outfrac) in enumerate(shapes):
 traffic["avg_hbm_bytes_per_call_llama_layer"] = tot_h / 4
 traffic["avg_algorithmic_bytes_per_call_llama_layer"] = tot_a / 4
 traffic["ratio"] = tot_h / tot_a
-(dst / "gemm_traffic.json").write_text(json.dumps(traffic, indent=1))
+(dst / OUT_NAME).write_text(json.dumps(traffic, indent=1))
 if rows.get("SQ_VALU_MFMA_BUSY_CYCLES"):
     by = lambda c: {r[0]: r for r in rows[c]}
     mf, gr = by("SQ_VALU_MFMA_BUSY_CYCLES"), by("GRBM_GUI_ACTIVE")
