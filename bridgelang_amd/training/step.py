@@ -174,6 +174,8 @@ class ParamStore:
         self.own = torch.zeros(max(n_own, 8), dtype=torch.bfloat16, device=dev) if sh else None
         self.grad = self.gshard = None
         self.gslots: List[torch.Tensor] = []
+        self.use_grad_slots = True          # TrainStep clears it when no collective runs (world 1): the "slice" is then the whole
+                                            # bucket and the weight-gradient GEMMs write the persistent buffer directly
         if not defer_grads:                 # TrainStep defers: it first gives the model's own decoder-layer allocation back
             self.alloc_grads()
         f = lambda: torch.zeros(max(lay.local_total, 8), dtype=torch.float32, device=dev)
@@ -207,7 +209,8 @@ class ParamStore:
         self.grad = torch.zeros(max(self._n_rep, 8), dtype=torch.float32, device=dev)
         if self.sharded_keys:
             self.gshard = torch.zeros(max(self._n_own, 8), dtype=torch.float32, device=dev)
-            self.gslots = [torch.zeros(self._slot_numel, dtype=torch.float32, device=dev) for _ in range(2)]
+            if self.use_grad_slots:
+                self.gslots = [torch.zeros(self._slot_numel, dtype=torch.float32, device=dev) for _ in range(2)]
 
     # ---- views ----
     def _replicated(self, buf: torch.Tensor, offset: int, numel: int) -> torch.Tensor:
@@ -232,6 +235,9 @@ class ParamStore:
 
     def grad_slot(self, b) -> torch.Tensor:
         """The transient full-size fp32 gradient of parameter-sharded bucket b (decoder layer l uses slot l % 2)."""
+        if not self.use_grad_slots:          # one rank, no collective: the rank's slice of the reduced gradient is the bucket itself
+            assert self.layout.world == 1
+            return self.reduced_grad(b)
         return self.gslots[int(b.key[len("llm.layer"):]) % 2][:b.numel]
 
     def reduced_grad(self, b) -> torch.Tensor:
@@ -359,6 +365,8 @@ class TrainStep:
         self._materialized = False
         if shard_params:                       # first: the model's layer allocation is given back before anything else is reserved
             self._setup_param_shards()
+        if st.grad is None:
+            st.use_grad_slots = self.comm.active
         st.alloc_grads()
         B, S, D, I, V, NL = batch, self.S, d.llm_dim, d.llm_inter, d.vocab, d.llm_layers
         Tn = B * S
@@ -608,6 +616,8 @@ class TrainStep:
         FSDP (fsdp.py:160-168), instead of the whole step."""
         def fn():
             st, lay, side = self.store, self.store.layout, self._comm_stream
+            if not st.use_grad_slots:                # nothing to reduce or move: the GEMMs wrote the persistent buffer
+                return
             b = self._layer_bucket(l)
             slot = st.grad_slot(b)
             ev = torch.cuda.Event()
