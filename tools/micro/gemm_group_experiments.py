@@ -2,7 +2,7 @@
 """A/B builds of the tile GEMM family with a different GROUP_M (row tiles per group of the grouped, XCD-contiguous tile
 order): python tools/micro/gemm_group_experiments.py 9 18 32 → tools/micro/build/gm<N>/libbridgelang_hip.so; compare with
 tools/ab_lib.sh (results are VALID: the order of tiles changes no arithmetic). The product source keeps one constant."""
-import subprocess, sys
+import re, subprocess, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[2]
 CSRC = ROOT / "bridgelang_amd" / "csrc"
@@ -11,8 +11,8 @@ for n in sys.argv[1:]:
     out = Path(__file__).resolve().parent / "build" / f"gm{n}"
     out.mkdir(parents=True, exist_ok=True)
     text = (CSRC / "gemm_bf16.hip").read_text()
-    assert text.count("constexpr int GROUP_M = 8;") == 1
-    (out / "gemm_bf16.hip").write_text(text.replace("constexpr int GROUP_M = 8;", f"constexpr int GROUP_M = {int(n)};"))
+    assert len(re.findall(r"constexpr int GROUP_M = \d+;", text)) == 1
+    (out / "gemm_bf16.hip").write_text(re.sub(r"constexpr int GROUP_M = \d+;", f"constexpr int GROUP_M = {int(n)};", text))
     flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", f"-I{ROOT / 'include'}", f"-I{CSRC}"]
     subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "-c", str(out / "gemm_bf16.hip"), "-o", str(out / "gemm_bf16.o")])
     objs = [str(out / "gemm_bf16.o")] + [str(CSRC / "build" / (s[:-4] + ".o")) for s in SRCS[1:]]
