@@ -115,3 +115,44 @@ def resize_image(image_u8: np.ndarray, resize_size: Tuple[int, int]) -> np.ndarr
     img = jpeg_round_trip(image_u8)
     h, w = resize_size
     return np.asarray(Image.fromarray(img).resize((w, h), Image.LANCZOS), dtype=np.uint8)
+
+
+# ---- the evaluation loops' policy call (experiments/robot/openvla_utils.py:115-172) --------------------------------------
+OPENVLA_V01_SYSTEM_PROMPT = ("A chat between a curious user and an artificial intelligence assistant. "
+                             "The assistant gives helpful, detailed, and polite answers to the user's questions.")
+
+
+def vla_prompt(base_vla_name: str, task_label: str) -> str:
+    """openvla_utils.py:157-163: the v0.1 chat form or the OpenVLA "In: … Out:" form."""
+    if "openvla-v01" in base_vla_name:
+        return f"{OPENVLA_V01_SYSTEM_PROMPT} USER: What action should the robot take to {task_label.lower()}? ASSISTANT:"
+    return f"In: What action should the robot take to {task_label.lower()}?\nOut:"
+
+
+def get_vla_action(vla, processor, base_vla_name: str, obs: dict, task_label: str, unnorm_key, center_crop: bool = False,
+                   on_device: bool = True):
+    """Drop-in for `get_vla_action` of the robot evaluation loops (same arguments, same returned action). `obs["full_image"]`
+    is a uint8 RGB frame [H, W, 3] (numpy, or a torch tensor already in HBM). With `on_device` (default) the frame goes to
+    the GPU once as uint8 and everything after runs there — centre crop + resize (bl_crop_resize_bilinear_u8), the image
+    processor's bicubic resize + dual normalisation (bl_resample_pass_u8, bl_preprocess_u8_bf16), predict_action — each
+    stage bit-identical to the host path (`on_device=False`: numpy crop → PIL → `processor(prompt, image)` as in the
+    reference), so both give the same action."""
+    import torch
+    from PIL import Image
+    prompt = vla_prompt(base_vla_name, task_label)
+    frame = obs["full_image"]
+    if not on_device:
+        image = np.asarray(frame.cpu() if torch.is_tensor(frame) else frame, dtype=np.uint8)
+        if center_crop:
+            image = center_crop_and_resize(image, 0.9, (224, 224))
+        inputs = processor(prompt, Image.fromarray(image).convert("RGB")).to(vla.device, dtype=torch.bfloat16)
+        return vla.predict_action(**inputs, unnorm_key=unnorm_key, do_sample=False)
+    dev = vla.device
+    frames = (frame if torch.is_tensor(frame) else torch.from_numpy(np.ascontiguousarray(frame, dtype=np.uint8))).to(dev)
+    frames = frames.view(1, *frames.shape[-3:]).contiguous()
+    if center_crop:
+        frames = center_crop_and_resize_gpu(frames, 0.9, (224, 224))
+    pixel_values = processor.image_processor.preprocess_frames_gpu(frames)
+    enc = processor.tokenizer(prompt, return_tensors="pt")
+    return vla.predict_action(input_ids=enc["input_ids"].to(dev), attention_mask=enc["attention_mask"].to(dev),
+                              pixel_values=pixel_values, unnorm_key=unnorm_key, do_sample=False)

@@ -262,3 +262,23 @@ def test_forward_language_only_inputs_embeds_and_hidden_states(saved, dev):
     assert torch.equal(out2.logits, out.logits)
     with pytest.raises(NotImplementedError):
         model(input_ids=ids.to(dev), output_attentions=True)
+
+
+@pytest.mark.parametrize("center_crop", [False, True])
+def test_get_vla_action_device_path_equals_host_path(saved, dev, center_crop):
+    """The robot loops' policy call (experiments/robot/openvla_utils.py:115-172) with the frame kept on the device — crop +
+    resize, bicubic resize, dual normalisation all as HIP kernels — returns exactly the action of the host path that
+    mirrors the reference (numpy crop → PIL → processor → predict_action), for a camera frame that is not 224 px."""
+    from bridgelang_amd.extern.hf.processing_prismatic import PrismaticImageProcessor, PrismaticProcessor
+    from bridgelang_amd.util.synthetic_tokenizer import SyntheticLlamaTokenizer
+    from bridgelang_amd.vla.eval_preprocess import get_vla_action, vla_prompt
+    _, model = saved
+    processor = PrismaticProcessor(PrismaticImageProcessor(), SyntheticLlamaTokenizer())
+    obs = {"full_image": np.random.RandomState(3).randint(0, 256, (256, 320, 3), dtype=np.uint8)}
+    assert vla_prompt("openvla-7b", "Pick Up the Cup") == "In: What action should the robot take to pick up the cup?\nOut:"
+    host = get_vla_action(model, processor, "openvla-7b", obs, "pick up the cup", "bridge_orig", center_crop=center_crop, on_device=False)
+    devp = get_vla_action(model, processor, "openvla-7b", obs, "pick up the cup", "bridge_orig", center_crop=center_crop)
+    assert host.shape == (7,) and np.array_equal(host, devp)
+    # a frame that already lives in HBM is taken as is
+    obs_dev = {"full_image": torch.from_numpy(obs["full_image"]).to(dev)}
+    assert np.array_equal(get_vla_action(model, processor, "openvla-7b", obs_dev, "pick up the cup", "bridge_orig", center_crop=center_crop), host)
