@@ -144,7 +144,8 @@ class ShardedOptimizerStrategy:
                  enable_mixed_precision_training: bool = True, reduce_in_full_precision: bool = False,
                  mixed_precision_dtype: torch.dtype = torch.bfloat16, worker_init_fn: Optional[Callable[[int], None]] = None,
                  sharding_strategy: str = "shard-grad-op", max_text_len: int = 48,
-                 recompute_activations: Optional[bool] = None, fp8_gemms: bool = False, **_: Any) -> None:
+                 recompute_activations: Optional[bool] = None, fp8_gemms: bool = False, fp8_wgrad: bool = False,
+                 **_: Any) -> None:
         if stage not in STAGES:
             raise ValueError(f"Stage `{stage}` is not supported")
         if sharding_strategy not in ("shard-grad-op", "full-shard"):
@@ -170,6 +171,7 @@ class ShardedOptimizerStrategy:
         # other stages, and "shard-grad-op", keep the bf16 weights replicated and shard gradients + optimizer state
         self.shard_params = sharding_strategy == "full-shard" and STAGES[stage][2] == "all"
         self.fp8_gemms = fp8_gemms      # extension (no reference flag): decoder-layer forward / dgrad GEMMs in e4m3
+        self.fp8_wgrad = fp8_wgrad and fp8_gemms     # … and their weight-gradient GEMMs too (TrainStep(fp8_wgrad=True))
         # the reference checkpoints every decoder layer when `enable_gradient_checkpointing` (fsdp.py:171-183) because
         # 80 GB parts cannot keep the activations; here they stay resident unless they would not fit (None = decide from
         # free HBM when the step is planned), and True / False force either form
@@ -190,7 +192,8 @@ class ShardedOptimizerStrategy:
         if self.shard_params:           # inference engines cached on the model hold the decoder-layer weights: drop them
             for cache in ("_engines", "_forward_engines"):
                 getattr(self.vlm, cache, {}).clear()
-        self.store = ParamStore(self.vlm.weights, self.stage, self.world, self.rank, shard_params=self.shard_params)
+        self.store = ParamStore(self.vlm.weights, self.stage, self.world, self.rank, shard_params=self.shard_params,
+                                defer_grads=True)      # gradient buffers come with the first TrainStep (after it frees the layers)
         self._ensure_engine(self.max_text_len)
 
     def _ensure_engine(self, text_len: int) -> TrainStep:
@@ -203,7 +206,7 @@ class ShardedOptimizerStrategy:
             self.step_engine = TrainStep(
                 self.vlm.weights, self.stage, self.per_device_batch_size, L, max_grad_norm=self.max_grad_norm,
                 weight_decay=self.weight_decay, store=self.store, recompute=self._want_recompute(L),
-                shard_params=self.shard_params, fp8=self.fp8_gemms, world=self.world, rank=self.rank,
+                shard_params=self.shard_params, fp8=self.fp8_gemms, fp8_wgrad=self.fp8_wgrad, world=self.world, rank=self.rank,
                 reduce_dtype=torch.float32 if self.reduce_in_full_precision else torch.bfloat16)
         return self.step_engine
 

@@ -58,6 +58,7 @@ class TrainConfig:
     tokenizer: str = "synthetic"
     dummy_length: int = 10000
     fp8_gemms: bool = False                        # decoder-layer forward / dgrad GEMMs on the e4m3 MFMA path (BASELINE configs[4])
+    fp8_wgrad: bool = False                        # with fp8_gemms: the weight-gradient GEMMs of those layers in e4m3 as well
     # fmt: on
 
     def __post_init__(self) -> None:
@@ -154,7 +155,7 @@ def train(cfg: TrainConfig) -> Path:
         weight_decay=cfg.weight_decay, max_grad_norm=cfg.max_grad_norm, lr_scheduler_type=cfg.lr_scheduler_type,
         warmup_ratio=cfg.warmup_ratio, enable_gradient_checkpointing=cfg.vla.enable_gradient_checkpointing,
         enable_mixed_precision_training=cfg.vla.enable_mixed_precision_training,
-        reduce_in_full_precision=cfg.vla.reduce_in_full_precision, fp8_gemms=cfg.fp8_gemms)
+        reduce_in_full_precision=cfg.vla.reduce_in_full_precision, fp8_gemms=cfg.fp8_gemms, fp8_wgrad=cfg.fp8_wgrad)
     strategy.run_setup(run_dir=run_dir, n_train_examples=len(vla_dataset))
     metrics = VLAMetrics(tuple(t for t in cfg.trackers if t != "wandb"), cfg.run_id, run_dir, cli.encode(cfg),
                          resume_step=cfg.resume_step, resume_epoch=cfg.resume_epoch)
