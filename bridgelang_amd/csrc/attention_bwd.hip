@@ -17,6 +17,7 @@
 // one LDS layout per staged operand (row reads conflict-free, transposing reads 2-way conflicted).
 #include "bl_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace bl_attention_bwd_impl {
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -335,6 +336,241 @@ int launch_bwd(const BwdArgs& a, hipStream_t s) {
   return BL_OK;
 }
 
+
+// ---- long sequences (Sq or Skv > 320: prompts beyond 55 tokens; the collator pads up to model_max_length = 2048,
+// prismatic/util/data_utils.py:101-142, configuration_prismatic.py:84) ----
+// Same arithmetic, tiled the other way round: a workgroup owns 8 tiles of the REGISTER-side operand (grid.y blocks of 128
+// query rows for dq, 128 key rows for dk/dv; one 16-row tile per wave, accumulators live in registers for the whole kernel)
+// and the LDS-side operand streams through in chunks of KC = 256 rows. P is recomputed from the stored log-sum-exp, so
+// chunks simply accumulate — no running max, no rescaling; the summation order over keys (dq) / queries (dk, dv) is the
+// whole-sequence kernels' order, so both forms give the same bits (tests/test_train_ops_gpu.py runs them against each other).
+constexpr int KC = 256;
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(512) void attn_bwd_dq_chunk_kernel(BwdArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int HDP = (HD + 31) / 32 * 32, KS = HDP / 32, KCH = HD / 8;
+  constexpr int ROWB = (HD <= 64) ? 128 : 256;
+  constexpr int DT = (HD + 15) / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* k_lds = smem;
+  char* v_lds = smem + KC * ROWB;
+  uint8_t* m_lds = (uint8_t*)(smem + 2 * KC * ROWB);          // key visibility of the staged chunk, one byte per key
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const int off = p.Skv - p.Sq;
+  const uint8_t* mrow = p.mask ? p.mask + (long)b * p.mask_bs : nullptr;
+  const uint16_t* kbase = p.k + (long)b * p.k_bs + (long)h * p.k_hs;
+  const uint16_t* vbase = p.v + (long)b * p.v_bs + (long)h * p.v_hs;
+
+  const int q0 = (blockIdx.y * 8 + wave) * 16, qrow = q0 + l15;          // tiles past the end: every guard below is false
+  int kv_hi = q0 < p.Sq ? p.Skv : 0, block_hi = p.Skv;
+  if (CAUSAL) {
+    kv_hi = q0 < p.Sq ? min(p.Skv, q0 + 16 + off) : 0;
+    block_hi = min(p.Skv, (int)blockIdx.y * 128 + 128 + off);
+  }
+  bf16x8_t qf[KS], dof[KS];
+  float dsum = 0.f;
+  {
+    const uint16_t* qp = p.q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qrow * p.q_rs;
+    const long oo = (long)b * p.o_bs + (long)h * p.o_hs + (long)qrow * p.o_rs;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int ch = lg + 4 * ks;
+      u32x4_t t = {0u, 0u, 0u, 0u}, g = {0u, 0u, 0u, 0u}, ov = {0u, 0u, 0u, 0u};
+      if (qrow < p.Sq && ch < KCH) {
+        t = *(const u32x4_t*)(qp + ch * 8);
+        g = *(const u32x4_t*)(p.dout + oo + ch * 8);
+        ov = *(const u32x4_t*)(p.o + oo + ch * 8);
+      }
+      qf[ks] = __builtin_bit_cast(bf16x8_t, t);
+      dof[ks] = __builtin_bit_cast(bf16x8_t, g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dsum += bflo(g[i]) * bflo(ov[i]) + bfhi(g[i]) * bfhi(ov[i]);
+    }
+  }
+  dsum += __shfl_xor(dsum, 16, 64);
+  dsum += __shfl_xor(dsum, 32, 64);
+  const long stat = ((long)b * p.H + h) * p.stat_rs + qrow;
+  if (lg == 0 && qrow < p.Sq) p.delta[stat] = dsum;
+  const float lse_q = qrow < p.Sq ? p.lse[stat] : INFINITY;
+
+  f32x4_t acc[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int key0 = 0; key0 < block_hi; key0 += KC) {
+    __syncthreads();                                              // the previous chunk has been consumed by every wave
+    stage_two<HD, ROWB>(k_lds, v_lds, kbase + (long)key0 * p.k_rs, p.k_rs, vbase + (long)key0 * p.v_rs, p.v_rs, KC,
+                        min(KC, p.Skv - key0), tid);
+    if (tid < KC) m_lds[tid] = (key0 + tid < p.Skv && (mrow == nullptr || mrow[key0 + tid] != 0)) ? 1 : 0;
+    __syncthreads();
+    for (int s2 = 0; s2 < KC / 32 && key0 + s2 * 32 < kv_hi; ++s2) {
+      float e[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int kt = 2 * s2 + half;
+        f32x4_t as = {0.f, 0.f, 0.f, 0.f}, ap = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          as = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<ROWB>(k_lds, kt * 16 + l15, lg + 4 * ks), qf[ks], as, 0, 0, 0);
+          ap = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<ROWB>(v_lds, kt * 16 + l15, lg + 4 * ks), dof[ks], ap, 0, 0, 0);
+        }
+        const uint32_t vis4 = *(const uint32_t*)(m_lds + kt * 16 + lg * 4);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int key = key0 + kt * 16 + lg * 4 + rr;
+          bool vis = ((vis4 >> (8 * rr)) & 0xffu) != 0;
+          if (CAUSAL) vis = vis && (key <= qrow + off);
+          const float pr = vis ? __builtin_amdgcn_exp2f(as[rr] * p.scale_log2e - lse_q) : 0.f;
+          e[half * 4 + rr] = pr * (ap[rr] - dsum);
+        }
+      }
+      const bf16x8_t dsf = pack8(e);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<ROWB>(k_lds, 32 * s2, dt, l15, lg), dsf, acc[dt], 0, 0, 0);
+    }
+  }
+  if (qrow < p.Sq) {
+    uint16_t* op = p.dq + (long)b * p.q_bs + (long)h * p.q_hs + (long)qrow * p.q_rs;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + lg * 4;
+      if (d < HD) {
+        u32x2_t w;
+        w[0] = pack2bf(acc[dt][0] * p.scale, acc[dt][1] * p.scale);
+        w[1] = pack2bf(acc[dt][2] * p.scale, acc[dt][3] * p.scale);
+        *(u32x2_t*)(op + d) = w;
+      }
+    }
+  }
+#endif
+}
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_chunk_kernel(BwdArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int HDP = (HD + 31) / 32 * 32, KS = HDP / 32, KCH = HD / 8;
+  constexpr int ROWB = (HD <= 64) ? 128 : 256;
+  constexpr int DT = (HD + 15) / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* q_lds = smem;
+  char* g_lds = smem + KC * ROWB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const int off = p.Skv - p.Sq;
+  const uint8_t* mrow = p.mask ? p.mask + (long)b * p.mask_bs : nullptr;
+  const uint16_t* qbase = p.q + (long)b * p.q_bs + (long)h * p.q_hs;
+  const uint16_t* gbase = p.dout + (long)b * p.o_bs + (long)h * p.o_hs;
+  const float* lse = p.lse + ((long)b * p.H + h) * p.stat_rs;
+  const float* delta = p.delta + ((long)b * p.H + h) * p.stat_rs;
+
+  const int k0 = (blockIdx.y * 8 + wave) * 16, key = k0 + l15;
+  bool key_ok = key < p.Skv;
+  if (mrow) key_ok = key_ok && (key < p.Skv ? mrow[key] != 0 : false);
+  bf16x8_t kf[KS], vf[KS];
+  {
+    const uint16_t* kp = p.k + (long)b * p.k_bs + (long)h * p.k_hs + (long)key * p.k_rs;
+    const uint16_t* vp = p.v + (long)b * p.v_bs + (long)h * p.v_hs + (long)key * p.v_rs;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int ch = lg + 4 * ks;
+      u32x4_t t = {0u, 0u, 0u, 0u}, u = {0u, 0u, 0u, 0u};
+      if (key < p.Skv && ch < KCH) {
+        t = *(const u32x4_t*)(kp + ch * 8);
+        u = *(const u32x4_t*)(vp + ch * 8);
+      }
+      kf[ks] = __builtin_bit_cast(bf16x8_t, t);
+      vf[ks] = __builtin_bit_cast(bf16x8_t, u);
+    }
+  }
+  f32x4_t dk[DT], dv[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) dk[i] = dv[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // first 32-row query step this wave / this workgroup needs (causal: rows below the key tile see nothing of it)
+  int s2_wave = 0, s2_block = 0;
+  if (CAUSAL) {
+    s2_wave = max(0, k0 - off) >> 5;
+    s2_block = max(0, (int)blockIdx.y * 128 - off) >> 5;
+  }
+  if (k0 >= p.Skv) s2_wave = (p.Sq + 31) >> 5;                       // tile past the end: no steps
+  for (int qc0 = (s2_block * 32) / KC * KC; qc0 < p.Sq; qc0 += KC) {
+    __syncthreads();
+    stage_two<HD, ROWB>(q_lds, g_lds, qbase + (long)qc0 * p.q_rs, p.q_rs, gbase + (long)qc0 * p.o_rs, p.o_rs, KC,
+                        min(KC, p.Sq - qc0), tid);
+    __syncthreads();
+    for (int s2 = max(s2_wave, qc0 >> 5); s2 * 32 < min(p.Sq, qc0 + KC); ++s2) {
+      float pe[8], de[8];
+      const int lrow = s2 * 32 - qc0;                                // row of this step inside the staged chunk
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int qt = 2 * s2 + half;
+        const f32x4_t l4 = *(const f32x4_t*)(lse + qt * 16 + lg * 4);     // stat rows are padded to 32
+        const f32x4_t d4 = *(const f32x4_t*)(delta + qt * 16 + lg * 4);
+        f32x4_t as = {0.f, 0.f, 0.f, 0.f}, ap = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          as = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<ROWB>(q_lds, lrow + half * 16 + l15, lg + 4 * ks), kf[ks], as, 0, 0, 0);
+          ap = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<ROWB>(g_lds, lrow + half * 16 + l15, lg + 4 * ks), vf[ks], ap, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int q = qt * 16 + lg * 4 + rr;
+          bool vis = key_ok && q < p.Sq;
+          if (CAUSAL) vis = vis && (key <= q + off);
+          const float pr = vis ? __builtin_amdgcn_exp2f(as[rr] * p.scale_log2e - l4[rr]) : 0.f;
+          pe[half * 4 + rr] = pr;
+          de[half * 4 + rr] = vis ? pr * (ap[rr] - d4[rr]) : 0.f;
+        }
+      }
+      const bf16x8_t pf = pack8(pe), dsf = pack8(de);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<ROWB>(g_lds, lrow, dt, l15, lg), pf, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<ROWB>(q_lds, lrow, dt, l15, lg), dsf, dk[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (key < p.Skv) {
+    uint16_t* kp = p.dk + (long)b * p.k_bs + (long)h * p.k_hs + (long)key * p.k_rs;
+    uint16_t* vp = p.dv + (long)b * p.v_bs + (long)h * p.v_hs + (long)key * p.v_rs;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + lg * 4;
+      if (d < HD) {
+        u32x2_t w;
+        w[0] = pack2bf(dk[dt][0] * p.scale, dk[dt][1] * p.scale);
+        w[1] = pack2bf(dk[dt][2] * p.scale, dk[dt][3] * p.scale);
+        *(u32x2_t*)(kp + d) = w;
+        w[0] = pack2bf(dv[dt][0], dv[dt][1]);
+        w[1] = pack2bf(dv[dt][2], dv[dt][3]);
+        *(u32x2_t*)(vp + d) = w;
+      }
+    }
+  }
+#endif
+}
+
+template <int HD, bool CAUSAL>
+int launch_bwd_chunked(const BwdArgs& a, hipStream_t s) {
+  constexpr int ROWB = (HD <= 64) ? 128 : 256;
+  constexpr int LDS = 2 * KC * ROWB + KC;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_chunk_kernel<HD, CAUSAL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_chunk_kernel<HD, CAUSAL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return BL_E_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_dq_chunk_kernel<HD, CAUSAL>), dim3(a.B * a.H, (a.Sq + 127) / 128), dim3(512), LDS, s, a);
+  hipLaunchKernelGGL((attn_bwd_dkv_chunk_kernel<HD, CAUSAL>), dim3(a.B * a.H, (a.Skv + 127) / 128), dim3(512), LDS, s, a);
+  return BL_OK;
+}
+
 }  // namespace bl_attention_bwd_impl
 using namespace bl_attention_bwd_impl;
 
@@ -342,7 +578,8 @@ extern "C" int bl_attention_backward_bf16(const bl_attn_desc* d, const bl_bf16* 
                                           bl_bf16* dq, bl_bf16* dk, bl_bf16* dv, void* stream) {
   if (!d || !d->q || !d->k || !d->v || !d->o || !dout || !lse || !delta || !dq || !dk || !dv) return BL_E_ARG;
   if (d->B <= 0 || d->H <= 0 || d->Sq <= 0 || d->Skv <= 0) return BL_E_SHAPE;
-  if (d->Sq > 320 || d->Skv > 320 || (d->causal && d->Skv < d->Sq)) return BL_E_SHAPE;
+  if (d->causal && d->Skv < d->Sq) return BL_E_SHAPE;
+  if ((long)d->B * d->H > 0x7fffffffL || (d->Sq + 127) / 128 > 65535 || (d->Skv + 127) / 128 > 65535) return BL_E_SHAPE;
   const int64_t st[] = {d->q_bs, d->q_hs, d->q_rs, d->k_bs, d->k_hs, d->k_rs, d->v_bs, d->v_hs, d->v_rs, d->o_bs, d->o_hs, d->o_rs};
   for (int64_t s : st) if (s % 8) return BL_E_ALIGN;
   const void* ptrs[] = {d->q, d->k, d->v, d->o, dout, dq, dk, dv, lse, delta};
@@ -357,7 +594,15 @@ extern "C" int bl_attention_backward_bf16(const bl_attn_desc* d, const bl_bf16* 
   a.scale = d->scale; a.scale_log2e = d->scale * 1.44269504088896340736f;
   hipStream_t s = (hipStream_t)stream;
   int r = BL_E_SHAPE;
-#define BL_BWD_CASE(HD) case HD: r = d->causal ? launch_bwd<HD, true>(a, s) : launch_bwd<HD, false>(a, s); break;
+  const bool chunked_only = getenv("BL_ATTN_BWD_CHUNKED") != nullptr;    // test aid: both forms on one shape (bit-identical)
+  // short sequences (every OpenVLA batch whose prompts stay under 56 tokens): one workgroup per (batch, head) with the
+  // LDS-side operand of the whole sequence resident; longer ones stream it in 256-row chunks
+  const bool whole = d->Sq <= 320 && d->Skv <= 320 && !chunked_only;
+#define BL_BWD_CASE(HD)                                                                                             \
+  case HD:                                                                                                          \
+    if (whole) r = d->causal ? launch_bwd<HD, true>(a, s) : launch_bwd<HD, false>(a, s);                            \
+    else r = d->causal ? launch_bwd_chunked<HD, true>(a, s) : launch_bwd_chunked<HD, false>(a, s);                  \
+    break;
   switch (d->head_dim) { BL_BWD_CASE(64) BL_BWD_CASE(72) BL_BWD_CASE(128) default: return BL_E_SHAPE; }
 #undef BL_BWD_CASE
   if (r != BL_OK) return r;

@@ -345,8 +345,8 @@ class TrainStep:
         self.w, self.dims, self.stage = weights, weights.dims, stage
         d = self.dims
         self.B, self.L, self.S = batch, prompt_len, prompt_len + d.n_patches
-        if self.S > 320:
-            raise ValueError("training sequences are limited to 320 positions (whole-sequence attention kernels)")
+        if self.S > d.max_pos:
+            raise ValueError(f"sequence of {self.S} positions exceeds the model's {d.max_pos} (model_max_length)")
         self.max_grad_norm, self.weight_decay, self.betas, self.eps = max_grad_norm, weight_decay, betas, eps
         if store is None:
             store = ParamStore(weights, stage, world, rank, extra=lora.plain_units() if lora is not None else None,

@@ -173,7 +173,9 @@ int bl_attention_lse_bf16(const bl_attn_desc* d, float* lse, void* stream);
  * `loss.backward()`, prismatic/training/strategies/base_strategy.py:300). d describes the forward call (o = its
  * output); dout uses o's strides; dq / dk / dv use q's / k's / v's strides (so they can alias the three thirds of a
  * fused dqkv row). lse from bl_attention_lse_bf16; delta is scratch of the same size, [B*H*pad32(Sq)] fp32.
- * Sq, Skv <= 320 (the whole-sequence kernels; all strides multiples of 8). */
+ * Any Sq, Skv (causal: Skv >= Sq): up to 320 positions one workgroup per (batch, head) holds the whole sequence in LDS;
+ * longer sequences (the collator pads to model_max_length = 2048, prismatic/util/data_utils.py:101-142) stream 256-row
+ * chunks against 128-row register blocks — same summation order, same bits. All strides multiples of 8. */
 int bl_attention_backward_bf16(const bl_attn_desc* d, const bl_bf16* dout, const float* lse, float* delta, bl_bf16* dq,
                                bl_bf16* dk, bl_bf16* dv, void* stream);
 /* Single-query decode attention over a KV cache; kv_len = number of valid keys (same for the whole batch). */

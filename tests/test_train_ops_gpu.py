@@ -159,7 +159,10 @@ def test_embed_backward(dev):
 
 
 @pytest.mark.parametrize("hd,H,S,causal,masked", [(128, 4, 290, True, False), (128, 2, 100, True, True), (128, 2, 33, True, False),
-                                                  (64, 4, 257, False, False), (72, 2, 256, False, False)])
+                                                  (64, 4, 257, False, False), (72, 2, 256, False, False),
+                                                  # beyond 320 positions: the chunked kernels (prompts of 56+ tokens)
+                                                  (128, 2, 406, True, False), (128, 2, 600, True, True), (128, 1, 1030, True, False),
+                                                  (64, 2, 406, False, False), (72, 2, 600, False, True)])
 def test_attention_backward(dev, hd, H, S, causal, masked):
     """dQ/dK/dV of the whole-sequence attention vs autograd over the oracle's attention (fused qkv-row strides, so the
     grads land in the three thirds of one dqkv buffer as the training step uses them)."""
@@ -169,7 +172,7 @@ def test_attention_backward(dev, hd, H, S, causal, masked):
     mask = None
     lens = [S] * B
     if masked:
-        lens = [S, 63, 17]
+        lens = [S, 63 if S <= 320 else S - 137, 17]
         mask = torch.zeros(B, S, dtype=torch.uint8)
         for i, n in enumerate(lens):
             mask[i, :n] = 1
@@ -210,6 +213,36 @@ def test_attention_backward(dev, hd, H, S, causal, masked):
     for i, n in enumerate(lens):
         for j, nm in enumerate("qkv"):
             grad_close(got[i, :n, j], ref[i, :n, j], f"d{nm} b={i}", tol=2.5e-2)
+
+
+@pytest.mark.parametrize("hd,H,S,causal", [(128, 3, 290, True), (128, 2, 37, True), (64, 2, 257, False), (72, 2, 300, False)])
+def test_attention_backward_chunked_equals_whole_sequence(dev, hd, H, S, causal, monkeypatch):
+    """The long-sequence (chunked) backward kernels keep the whole-sequence kernels' summation order: forced onto a short
+    sequence (BL_ATTN_BWD_CHUNKED) they must reproduce dq / dk / dv and delta bit for bit."""
+    from bridgelang_amd import train_ops as T
+    B, D = 2, H * hd
+    Q, G = dv(rand_bf16((B * S, 3 * D), 11), dev), dv(rand_bf16((B * S, D), 12), dev)
+    mask = torch.ones(B, S, dtype=torch.uint8)
+    mask[1, S - 9:] = 0
+    pad = (S + 31) // 32 * 32
+    o = torch.zeros(B * S, D, dtype=torch.bfloat16, device=dev)
+    lse = torch.zeros(B * H * pad, device=dev)
+    st, so = (S * 3 * D, hd, 3 * D), (S * D, hd, D)
+    kw = dict(B=B, H=H, Sq=S, Skv=S, head_dim=hd, q_strides=st, k_strides=st, v_strides=st, o_strides=so, causal=causal,
+              key_mask=mask.to(dev))
+    T.attention_lse(Q, Q[:, D:], Q[:, 2 * D:], o, lse, **kw)
+    outs = []
+    for chunked in (False, True):
+        if chunked:
+            monkeypatch.setenv("BL_ATTN_BWD_CHUNKED", "1")
+        delta = torch.zeros(B * H * pad, device=dev)
+        dqkv = torch.zeros(B * S, 3 * D, dtype=torch.bfloat16, device=dev)
+        T.attention_backward(Q, Q[:, D:], Q[:, 2 * D:], o, G, lse, delta, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], **kw)
+        torch.cuda.synchronize()
+        outs.append((dqkv.cpu(), delta.cpu()))
+    monkeypatch.delenv("BL_ATTN_BWD_CHUNKED")
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
+    assert torch.equal(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize("rows,dim", [(261 * 2, 256), (300, 1152)])

@@ -314,8 +314,9 @@ def test_recompute_rejected_with_adapters(dev):
 
 
 def test_edge_cases_max_length_and_unsupervised_sample(dev):
-    """(i) the longest plannable sequence (S = 320 = 256 patches + 64 text tokens) still matches autograd; (ii) a sample
-    with no supervised token contributes nothing (HF ignore_index semantics); (iii) over-long plans are rejected."""
+    """(i) the longest sequence of the whole-sequence attention kernels (S = 320 = 256 patches + 64 text tokens) still matches
+    autograd; (ii) a sample with no supervised token contributes nothing (HF ignore_index semantics); (iii) plans beyond the
+    model's position table (model_max_length, configuration_prismatic.py:84) are rejected."""
     from bridgelang_amd.training.step import TrainStep, trainable_names
     from bridgelang_amd.weights import allocate, tiny_dims
     dims = tiny_dims()
@@ -342,4 +343,37 @@ def test_edge_cases_max_length_and_unsupervised_sample(dev):
     dl = ts.dlogits.view(B, ts.S, -1)
     assert dl[1].abs().max().item() == 0.0 and dl[0].abs().max().item() > 0
     with pytest.raises(ValueError):
-        TrainStep(w, "vla-train", B, 65, store=ts.store)
+        TrainStep(w, "vla-train", B, dims.max_pos - 256 + 1, store=ts.store)
+
+
+@pytest.mark.parametrize("stage,L", [("vla-train", 150), ("vla-full-train", 344)])
+def test_long_prompts_beyond_320_positions(dev, stage, L):
+    """The collator pads to the longest sample up to model_max_length = 2048 (data_utils.py:101-142) and run_vla_training
+    trains on whatever comes (base_strategy.py:284-366): a 150-token prompt (S = 406) and a 344-token one (S = 600) go
+    through the chunked attention kernels — gradients vs autograd over the oracle, then two optimizer steps on the batch."""
+    from bridgelang_amd.training.step import TrainStep, trainable_names
+    from bridgelang_amd.weights import allocate, tiny_dims
+    dims = tiny_dims()
+    w = allocate(dims, dev).fill_synthetic(seed=9)
+    sd = {k: v.float().cpu() for k, v in w.state_dict().items()}
+    B = 2
+    ids, mask, labels, pv = make_batch(dims, B, L, seed=5)            # ragged: the second sample is 3 tokens shorter
+    ts = TrainStep(w, stage, B, L)
+    assert ts.S == L + 256 > 320
+    ts.set_batch(ids, mask, pv, labels)
+    loss = ts.forward().item()
+    ts.backward()
+    names = trainable_names(w, stage)
+    for n in names:
+        sd[n].requires_grad_(True)
+    ref = oracle_loss(sd, dims, ids, mask, labels, pv)
+    ref.backward()
+    assert abs(loss - ref.item()) <= 2e-3 * abs(ref.item())
+    worst = 1.0
+    for n in names:
+        c = cos(ts.store.named_grad(n).float().cpu(), sd[n].grad)
+        worst = min(worst, c)
+        assert c > 0.99, f"{n}: cosine {c:.5f}"
+    print(f"[{stage} S={ts.S}] loss {loss:.5f} vs oracle {ref.item():.5f}; worst gradient cosine {worst:.5f}")
+    losses = [ts.step(2e-3)[0].item() for _ in range(3)]
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
