@@ -13,13 +13,19 @@ the build container's CPU (tests/golden/make_cfg_7b.py → tests/golden/cfg1_7b_
 Bars (north_star: action-bin ids bit-exact, logits within tolerance). The only legitimate difference between the HIP
 path and the oracle is the fp32 summation order inside GEMMs / softmax / norms, which flips individual bf16 roundings.
 How far two CORRECT orders drift apart on each checkpoint is MEASURED, on the oracle alone, by running it in a second
-summation order (tests/golden/noise_floor_7b_*.npz, tests/test_noise_floor_cpu.py): 3.9 % of the logit scale on "init",
-2.8 % on "decisive", 0.65 % on "margin". Hence:
-  * logits: max |Δlogit| / max |logit| over every comparable (sequence, step) must stay within 1.5 x that measured
-    oracle-vs-oracle′ floor (LOGIT_TOL, read from the fixture);
-  * ids on "init" / "decisive": must EQUAL the oracle's at every step whose oracle top-2 gap exceeds 2 x the floor
-    (GAP_MIN — a gap no pair of noisy logits can close); the number of steps below that is printed. A sequence stops
-    being comparable after its first differing id;
+summation order (tests/golden/noise_floor_7b_*.npz, tests/test_noise_floor_cpu.py): 3.92 % of the logit scale on "init",
+2.78 % on "decisive", 1.40 % on "margin" at batch 1; 3.1 % on "decisive" and the figure printed below on "init" at batch 16
+(tests/golden/make_noise_floor_b16.py: oracle′ on the batch-16 fixtures' own inputs, teacher-forced on the oracle's ids).
+The bars are CONSTANTS of this file (the fixtures must reproduce the pinned floors, they do not set the bars):
+  * logits: max |Δlogit| / max |logit| over every comparable (sequence, step) ≤ LOGIT_TOL = min(the bar every earlier
+    round passed, 1.5 x the measured floor): 4.5e-2 init, 3.5e-2 decisive, 2.1e-2 margin;
+  * ids on "init" / "decisive": must EQUAL the oracle's at every step whose oracle top-2 gap exceeds GAP_MIN = 2 % of the
+    logit scale, and the number of steps so asserted has a stated lower bound per fixture. A sequence stops being
+    comparable after its first differing id;
+  * the steps below GAP_MIN at batch 16 are compared with what oracle′ does on the SAME 112 (sequence, step) pairs: every
+    HIP id that differs from the oracle's must be one of the oracle's two best tokens at that step(the runner-up), the number of
+    HIP flips among the comparable steps may not exceed oracle′'s own flip count by more than a stated binomial margin, and
+    the per-step logit difference stays within 1.5 x the batch-16 floor;
   * ids on "margin": all of them, `torch.equal`.
 """
 from pathlib import Path
@@ -33,9 +39,17 @@ pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
 from test_noise_floor_cpu import floor_of
 
-FLOOR = {r: floor_of(r) for r in ("init", "decisive", "margin")}     # oracle vs oracle′ (second summation order), measured
-LOGIT_TOL = {r: 1.5 * f for r, f in FLOOR.items()}                   # HIP vs oracle may be at most 1.5 x that
-GAP_MIN = {r: 2.0 * f for r, f in FLOOR.items()}                     # ids asserted where the oracle's gap is beyond the noise
+# oracle vs oracle′ (second summation order) at batch 1, as measured in round 3 — PINNED here; the fixtures must reproduce
+# them (test_pinned_floors_match_the_fixtures), so regenerating a fixture cannot move a bar
+FLOOR = {"init": 3.92e-2, "decisive": 2.78e-2, "margin": 1.40e-2}
+LOGIT_TOL = {"init": 4.5e-2, "decisive": 3.5e-2, "margin": 2.1e-2}   # min(the bar of rounds 1-2, 1.5 x FLOOR)
+GAP_MIN = {"init": 0.02, "decisive": 0.02}                           # ids asserted wherever the oracle's gap exceeds 2 % of the scale
+MIN_ID_CHECKED = {("decisive", 1): 7, ("init", 1): 6, ("decisive", 16): 70, ("init", 16): 55}   # measured 7 / 6 / 78 / 62
+
+
+def test_pinned_floors_match_the_fixtures():
+    for r, f in FLOOR.items():
+        assert abs(floor_of(r) - f) <= 0.02 * f, (r, floor_of(r), f)
 
 
 def _bf16_bits_to_f32(a: np.ndarray) -> torch.Tensor:
@@ -71,11 +85,14 @@ def _run(recipe, batch, dev):
     return fx, got_ids, got_logits
 
 
-def _compare(fx, got_ids, got_logits, recipe, tag):
+def _compare(fx, got_ids, got_logits, recipe, tag, nf=None):
+    """`nf`: the oracle′ run on the same inputs (noise_floor_7b_<recipe>_b16_s0_tree8.npz) — the yardstick for the steps whose
+    oracle gap is below GAP_MIN."""
     want_ids = torch.from_numpy(fx["ids"])
     gap = torch.from_numpy(fx["top2_gap"]) / torch.from_numpy(fx["logit_scale"])
     B, T = want_ids.shape
     worst, exact_frac, checked, near_ties, id_checked = 0.0, [], 0, 0, 0
+    flips, per_step = [], []
     for b in range(B):
         for t in range(T):
             if t > 0 and not torch.equal(got_ids[b, :t], want_ids[b, :t]):
@@ -89,8 +106,11 @@ def _compare(fx, got_ids, got_logits, recipe, tag):
                 ref = _bf16_bits_to_f32(fx["topk_vals_bf16"][b, t])
                 have = got_logits[b, t][idx]
             worst = max(worst, ((have - ref).abs().max() / scale).item())
+            per_step.append(((have - ref).abs().max() / scale).item())
             exact_frac.append((have == ref).float().mean().item())
             checked += 1
+            if got_ids[b, t] != want_ids[b, t]:
+                flips.append((b, t, float(gap[b, t])))
             if gap[b, t] > GAP_MIN[recipe]:
                 id_checked += 1
                 assert got_ids[b, t] == want_ids[b, t], (f"{tag} seq {b} step {t}: id {int(got_ids[b, t])} != oracle "
@@ -98,10 +118,27 @@ def _compare(fx, got_ids, got_logits, recipe, tag):
             else:
                 near_ties += 1
     print(f"\n{tag}: {checked} (sequence, step) logit rows compared, max |dlogit|/scale {worst:.2e} "
-          f"(oracle self-noise {FLOOR[recipe]:.2e}, bound 1.5x = {LOGIT_TOL[recipe]:.2e}), bit-equal logits {np.mean(exact_frac):.3f}; "
-          f"ids equal on all {id_checked} steps with gap > 2x noise = {GAP_MIN[recipe]:.3f}, {near_ties} steps inside the noise; "
-          f"all ids equal: {bool(torch.equal(got_ids, want_ids))}")
+          f"(oracle self-noise at B = 1 {FLOOR[recipe]:.2e}, bound {LOGIT_TOL[recipe]:.2e}), bit-equal logits {np.mean(exact_frac):.3f}; "
+          f"ids equal on all {id_checked} steps with oracle gap > {GAP_MIN[recipe]:.3f}, {near_ties} steps below it; "
+          f"HIP flips {len(flips)} at gaps {[round(g, 4) for _, _, g in flips]}; all ids equal: {bool(torch.equal(got_ids, want_ids))}")
     assert worst <= LOGIT_TOL[recipe]
+    assert id_checked >= MIN_ID_CHECKED[(recipe, B)], "the id check may not shrink"
+    if nf is not None:
+        # what a second CORRECT implementation does on these very (sequence, step) pairs
+        assert np.array_equal(nf["primary_ids"], fx["ids"]) and str(nf["recipe"]) == recipe
+        o_flips = int(nf["flips"].sum())
+        floor16 = float(nf["dlogit_over_scale"].max())
+        margin = int(np.ceil(2.0 * np.sqrt(o_flips + 1.0)))          # two binomial standard deviations at oracle′'s own rate
+        top2 = fx["topk_idx"][:, :, :2]
+        runner_up = all(int(got_ids[b, t]) in top2[b, t].tolist() for b, t, _ in flips)
+        print(f"{tag}: oracle′ (tree8) on the same pairs: {o_flips} flips of {nf['flips'].size} at gaps "
+              f"{[round(float(g), 4) for g in (fx['top2_gap'] / fx['logit_scale'])[nf['flips']]]}, max |dlogit|/scale {floor16:.2e}; "
+              f"HIP: {len(flips)} flips of {checked} comparable (allowed {o_flips} + {margin}), every flip lands on the oracle's "
+              f"runner-up: {runner_up}, worst per-step |dlogit|/scale {max(per_step):.2e} (1.5 x B=16 floor = {1.5 * floor16:.2e})")
+        assert runner_up, "a differing id must be the oracle's runner-up at that step"
+        assert len(flips) <= o_flips + margin, "the HIP path flips more ids than a second correct implementation does"
+        assert max(g for _, _, g in flips) <= 2.0 * floor16 if flips else True, "an id may flip only inside the logit noise"
+        assert max(per_step) <= 1.5 * floor16
     return near_ties, checked
 
 
@@ -111,6 +148,7 @@ def test_cfg1_batch1_full_size_vs_oracle_fixture(dev, recipe):
     fx, got_ids, got_logits = _run(recipe, 1, dev)
     near, checked = _compare(fx, got_ids, got_logits, recipe, f"cfg1 7B {recipe} B=1")
     if recipe == "decisive":
+        assert near == 0
         assert checked == 7 and torch.equal(got_ids, torch.from_numpy(fx["ids"])), \
             "the decisive checkpoint reproduces all 7 action-token ids of this sequence"
         assert ((got_ids >= 31744) & (got_ids < 32000)).all(), "greedy ids must be action tokens on this checkpoint"
@@ -120,7 +158,8 @@ def test_cfg1_batch1_full_size_vs_oracle_fixture(dev, recipe):
 def test_cfg2_batch16_full_size_vs_oracle_fixture(dev, recipe):
     """BASELINE configs[1]'s batch of 16 at full 7B size: ids + the oracle's top-32 logits per step."""
     fx, got_ids, got_logits = _run(recipe, 16, dev)
-    near, checked = _compare(fx, got_ids, got_logits, recipe, f"cfg2 7B {recipe} B=16")
+    nf = np.load(GOLD / f"noise_floor_7b_{recipe}_b16_s0_tree8.npz")
+    near, checked = _compare(fx, got_ids, got_logits, recipe, f"cfg2 7B {recipe} B=16", nf=nf)
     if recipe == "decisive":
         assert checked >= 90, "most of the 112 (sequence, step) pairs must be comparable on the decisive checkpoint"
 
