@@ -1515,7 +1515,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   // B = 16: 204 / 224 tiles, 45 → 39 µs; round 3, the narrow ViT layers at the training batch of 32 images — 132 / 160 tiles
   // for M = 8352 / 8192, N = 1024 / 1152 — where the 128 kernel needs 528 / 576 > 512 workgroup slots: 104 → 82 µs at
   // K = 4096, 35 → 30 µs at K = 1024)
-  bool big = big_tiles >= 128 && p.K >= 512;
+  static const int big_min = getenv("BL_GEMM_BIG_MIN") ? atoi(getenv("BL_GEMM_BIG_MIN")) : 128;   // A/B aid
+  bool big = big_tiles >= big_min && p.K >= 512;
   if (force) big = force[0] == '2';
   static const bool no_mid = getenv("BL_GEMM_NO_MID") != nullptr;      // A/B aid
   // M <= 320: the weight-streaming mid kernels; up to 640 rows (B = 2 prefill) the 160-row mid2 kernel still beats the

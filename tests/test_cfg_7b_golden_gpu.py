@@ -23,7 +23,7 @@ The bars are CONSTANTS of this file (the fixtures must reproduce the pinned floo
     logit scale, and the number of steps so asserted has a stated lower bound per fixture. A sequence stops being
     comparable after its first differing id;
   * the steps below GAP_MIN at batch 16 are compared with what oracle′ does on the SAME 112 (sequence, step) pairs: every
-    HIP id that differs from the oracle's must be one of the oracle's two best tokens at that step(the runner-up), the number of
+    HIP id that differs from the oracle's must be a token the oracle holds within 2 x the noise of its best one, the number of
     HIP flips among the comparable steps may not exceed oracle′'s own flip count by more than a stated binomial margin, and
     the per-step logit difference stays within 1.5 x the batch-16 floor;
   * ids on "margin": all of them, `torch.equal`.
@@ -129,13 +129,18 @@ def _compare(fx, got_ids, got_logits, recipe, tag, nf=None):
         o_flips = int(nf["flips"].sum())
         floor16 = float(nf["dlogit_over_scale"].max())
         margin = int(np.ceil(2.0 * np.sqrt(o_flips + 1.0)))          # two binomial standard deviations at oracle′'s own rate
-        top2 = fx["topk_idx"][:, :, :2]
-        runner_up = all(int(got_ids[b, t]) in top2[b, t].tolist() for b, t, _ in flips)
+        behind = []                                                  # how far behind its best token the ORACLE holds the HIP id
+        for b, t, _ in flips:
+            idx = fx["topk_idx"][b, t].tolist()
+            assert int(got_ids[b, t]) in idx, "a differing id must be among the oracle's top-32 at that step"
+            vals = _bf16_bits_to_f32(fx["topk_vals_bf16"][b, t])
+            behind.append(float(vals[0] - vals[idx.index(int(got_ids[b, t]))]) / float(fx["logit_scale"][b, t]))
+        runner_up = all(x <= 2.0 * floor16 for x in behind)
         print(f"{tag}: oracle′ (tree8) on the same pairs: {o_flips} flips of {nf['flips'].size} at gaps "
               f"{[round(float(g), 4) for g in (fx['top2_gap'] / fx['logit_scale'])[nf['flips']]]}, max |dlogit|/scale {floor16:.2e}; "
-              f"HIP: {len(flips)} flips of {checked} comparable (allowed {o_flips} + {margin}), every flip lands on the oracle's "
-              f"runner-up: {runner_up}, worst per-step |dlogit|/scale {max(per_step):.2e} (1.5 x B=16 floor = {1.5 * floor16:.2e})")
-        assert runner_up, "a differing id must be the oracle's runner-up at that step"
+              f"HIP: {len(flips)} flips of {checked} comparable (allowed {o_flips} + {margin}), every flip lands on a token "
+              f"the oracle holds within 2 x that floor of its best ({[round(x, 4) for x in behind]}): {runner_up}, worst per-step |dlogit|/scale {max(per_step):.2e} (1.5 x B=16 floor = {1.5 * floor16:.2e})")
+        assert runner_up, "a differing id must be a token the oracle itself holds inside the noise band of its best one"
         assert len(flips) <= o_flips + margin, "the HIP path flips more ids than a second correct implementation does"
         assert max(g for _, _, g in flips) <= 2.0 * floor16 if flips else True, "an id may flip only inside the logit noise"
         assert max(per_step) <= 1.5 * floor16
