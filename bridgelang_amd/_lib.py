@@ -18,6 +18,7 @@ _ERR = {BL_E_SHAPE: "BL_E_SHAPE (unsupported shape)", BL_E_ALIGN: "BL_E_ALIGN (a
 
 # enum bl_epilogue
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_RES, EPI_SWIGLU, EPI_F32, EPI_F32_BF16R = range(8)
+EPI_SWIGLU_KEEP, EPI_BIAS_GELU_KEEP, EPI_SWIGLU_BWD, EPI_GELU_BWD = range(8, 12)     # training-step forms (bl_gemm_bf16)
 
 
 class GemmDesc(C.Structure):
@@ -37,6 +38,8 @@ class GemmDesc(C.Structure):
         ("a_norm_eps", C.c_float),
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_int64),
+        ("C2", C.c_void_p),
+        ("ldc2", C.c_int64),
     ]
 
 

@@ -49,6 +49,17 @@ __device__ __forceinline__ float erf_as(float x) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 // x·sigmoid(x) with the hardware exp2 / reciprocal (≈ 3 fp32 ulp): the SwiGLU epilogue evaluates it 1.6e9 times per step
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// Backward of act = bf16(silu(g)) * u for one (gate, up) pair given d = dL/d act — ONE definition for
+// bl_swiglu_backward_bf16 and the BL_EPI_SWIGLU_BWD GEMM epilogue (bit-identical paths).
+__device__ __forceinline__ void swiglu_bwd_pair(float g, float u, float d, float& dg, float& du) {
+  const float sg = 1.0f / (1.0f + expf(-g));
+  dg = d * u * (sg * (1.0f + g * (1.0f - sg)));
+  du = d * rbf(g * sg);
+}
+// d/dx of the exact-erf GELU (bl_gelu_backward_bf16 and the BL_EPI_GELU_BWD epilogue)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
 
 // ---- launch helpers -------------------------------------------------------------------------------------------
 #define BL_CHECK_LAUNCH()                                   \

@@ -1737,6 +1737,10 @@ extern "C" int bl_gemm_bf16(const bl_gemm_desc* d, void* stream) {
     case BL_EPI_SWIGLU: return launch_gemm<BL_EPI_SWIGLU>(a, s);
     case BL_EPI_F32: return launch_gemm<BL_EPI_F32>(a, s);
     case BL_EPI_F32_BF16R: return launch_gemm<BL_EPI_F32_BF16R>(a, s);
+    case BL_EPI_SWIGLU_KEEP: return launch_gemm<BL_EPI_SWIGLU_KEEP>(a, s);
+    case BL_EPI_BIAS_GELU_KEEP: return launch_gemm<BL_EPI_BIAS_GELU_KEEP>(a, s);
+    case BL_EPI_SWIGLU_BWD: return launch_gemm<BL_EPI_SWIGLU_BWD>(a, s);
+    case BL_EPI_GELU_BWD: return launch_gemm<BL_EPI_GELU_BWD>(a, s);
     default: return BL_E_ARG;
   }
 }

@@ -18,6 +18,7 @@ struct GemmArgs {
   int tail_base;   // >= 0: this launch covers big (256x256) tiles tail_base.. of the tiles_m x tiles_n big-tile grid
   const float* qa; const float* qw;   // fp8 GEMM: per-row activation / per-column weight dequantisation scales
   int fold_ks;   // gemm_mid_kernel<SK>: MFMA k-steps per K-slice (skinny summation order); 0 = off
+  uint16_t* C2; long ldc2;   // second output of the *_KEEP training epilogues
 };
 
 __device__ __forceinline__ int out_row_of(const GemmArgs& p, int m) {
@@ -38,6 +39,33 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n,
     if constexpr (EPI == BL_EPI_F32_BF16R) acc = (f32x4_t){rbf(acc[0]), rbf(acc[1]), rbf(acc[2]), rbf(acc[3])};
     *(f32x4_t*)c = acc;
     return;
+  } else if constexpr (EPI == BL_EPI_SWIGLU_KEEP) {
+    // training forward of gate/up: the pre-activations stay (autograd's saved tensor), the activation goes to C2
+    const float g0 = rbf(acc[0]), u0 = rbf(acc[1]), g1 = rbf(acc[2]), u1 = rbf(acc[3]);
+    u32x2_t o; o[0] = pack2bf(g0, u0); o[1] = pack2bf(g1, u1);
+    *(u32x2_t*)((uint16_t*)p.C + (long)orow * p.ldc + n) = o;
+    *(uint32_t*)(p.C2 + (long)orow * p.ldc2 + (n >> 1)) = pack2bf(rbf(silu_f(g0)) * u0, rbf(silu_f(g1)) * u1);
+    return;
+  } else if constexpr (EPI == BL_EPI_SWIGLU_BWD) {
+    // acc = dL/d act[m, n..n+3] (input gradient of down_proj); res = the saved gate/up pairs of those 4 columns
+    float v[8], o[8];
+    const u32x4_t q = *(const u32x4_t*)(p.res + (long)m * p.ldres + 2 * n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = bflo(q[i]); v[2 * i + 1] = bfhi(q[i]); }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) swiglu_bwd_pair(v[2 * e], v[2 * e + 1], rbf(acc[e]), o[2 * e], o[2 * e + 1]);
+    u32x4_t w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = pack2bf(o[2 * i], o[2 * i + 1]);
+    *(u32x4_t*)((uint16_t*)p.C + (long)orow * p.ldc + 2 * n) = w;
+    return;
+  } else if constexpr (EPI == BL_EPI_GELU_BWD) {
+    const u32x2_t t = *(const u32x2_t*)(p.res + (long)m * p.ldres + n);
+    u32x2_t o;
+    o[0] = pack2bf(rbf(acc[0]) * gelu_erf_grad(bflo(t[0])), rbf(acc[1]) * gelu_erf_grad(bfhi(t[0])));
+    o[1] = pack2bf(rbf(acc[2]) * gelu_erf_grad(bflo(t[1])), rbf(acc[3]) * gelu_erf_grad(bfhi(t[1])));
+    *(u32x2_t*)((uint16_t*)p.C + (long)orow * p.ldc + n) = o;
+    return;
   } else if constexpr (EPI == BL_EPI_SWIGLU) {
     // rows 2j / 2j+1 of W are gate_j / up_j → regs (0,1) and (2,3) are (gate, up) pairs
     const float g0 = rbf(acc[0]), u0 = rbf(acc[1]), g1 = rbf(acc[2]), u1 = rbf(acc[3]);
@@ -47,13 +75,19 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n,
     return;
   } else {
     float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-    if constexpr (EPI == BL_EPI_BIAS || EPI == BL_EPI_BIAS_GELU || EPI == BL_EPI_BIAS_RES) {
+    if constexpr (EPI == BL_EPI_BIAS || EPI == BL_EPI_BIAS_GELU || EPI == BL_EPI_BIAS_RES || EPI == BL_EPI_BIAS_GELU_KEEP) {
       const u32x2_t b = *(const u32x2_t*)(p.bias + n);
       v[0] += bflo(b[0]); v[1] += bfhi(b[0]); v[2] += bflo(b[1]); v[3] += bfhi(b[1]);
     }
     if constexpr (EPI == BL_EPI_BIAS_GELU) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = gelu_erf(rbf(v[i]));
+    }
+    if constexpr (EPI == BL_EPI_BIAS_GELU_KEEP) {     // C keeps t = bf16(acc + bias), C2 gets gelu(t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = rbf(v[i]);
+      u32x2_t a2; a2[0] = pack2bf(gelu_erf(v[0]), gelu_erf(v[1])); a2[1] = pack2bf(gelu_erf(v[2]), gelu_erf(v[3]));
+      *(u32x2_t*)(p.C2 + (long)orow * p.ldc2 + n) = a2;
     }
     if constexpr (EPI == BL_EPI_BIAS_RES || EPI == BL_EPI_RES) {
 #pragma unroll
@@ -82,9 +116,16 @@ inline int fill_gemm_args(const bl_gemm_desc* d, GemmArgs& a) {
   if (!bl_aligned16(d->A) || !bl_aligned16(d->W) || (((uintptr_t)d->C) & 15)) return BL_E_ALIGN;
   const int epi = d->epilogue;
   if (epi == BL_EPI_SWIGLU) { if ((d->ldc % 2) || (d->N % 32)) return BL_E_ALIGN; }
+  else if (epi == BL_EPI_SWIGLU_BWD) { if (d->ldc % 8) return BL_E_ALIGN; }
   else if (d->ldc % 4) return BL_E_ALIGN;
-  if ((epi == BL_EPI_BIAS || epi == BL_EPI_BIAS_GELU || epi == BL_EPI_BIAS_RES) && !d->bias) return BL_E_ARG;
-  if ((epi == BL_EPI_BIAS_RES || epi == BL_EPI_RES) && (!d->res || (d->ldres % 4))) return BL_E_ARG;
+  if ((epi == BL_EPI_BIAS || epi == BL_EPI_BIAS_GELU || epi == BL_EPI_BIAS_RES || epi == BL_EPI_BIAS_GELU_KEEP) && !d->bias) return BL_E_ARG;
+  if ((epi == BL_EPI_BIAS_RES || epi == BL_EPI_RES || epi == BL_EPI_GELU_BWD) && (!d->res || (d->ldres % 4))) return BL_E_ARG;
+  if (epi == BL_EPI_SWIGLU_BWD && (!d->res || (d->ldres % 8) || !bl_aligned16(d->res) || d->res_row_mod || d->out_group)) return BL_E_ARG;
+  if (epi == BL_EPI_GELU_BWD && (d->res_row_mod || d->out_group)) return BL_E_ARG;
+  if (epi == BL_EPI_SWIGLU_KEEP || epi == BL_EPI_BIAS_GELU_KEEP) {
+    if (!d->C2 || (((uintptr_t)d->C2) & 15)) return BL_E_ARG;
+    if (epi == BL_EPI_SWIGLU_KEEP ? ((d->ldc2 % 2) || (d->N % 32)) : (d->ldc2 % 4) != 0) return BL_E_ALIGN;
+  }
   if (d->out_group < 0 || (d->out_group > 0 && d->out_stride <= 0)) return BL_E_SHAPE;
   a.A = d->A; a.W = d->W; a.C = d->C; a.bias = d->bias; a.scale = d->scale; a.res = d->res;
   a.lda = d->lda; a.ldw = d->ldw; a.ldc = d->ldc; a.ldres = d->ldres;
@@ -96,6 +137,7 @@ inline int fill_gemm_args(const bl_gemm_desc* d, GemmArgs& a) {
   a.norm_w = d->a_norm_weight; a.norm_eps = d->a_norm_eps;
   a.qa = a.qw = nullptr;
   a.fold_ks = 0;
+  a.C2 = (uint16_t*)d->C2; a.ldc2 = d->ldc2;
   return BL_OK;
 }
 

@@ -292,10 +292,7 @@ __global__ void swiglu_bwd_kernel(const uint16_t* gu, long ldg, const uint16_t* 
     const float da[4] = {bflo(dq[0]), bfhi(dq[0]), bflo(dq[1]), bfhi(dq[1])};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float g = v[2 * e], u = v[2 * e + 1];
-      const float sg = 1.0f / (1.0f + expf(-g));
-      o[2 * e] = da[e] * u * (sg * (1.0f + g * (1.0f - sg)));      // d gate
-      o[2 * e + 1] = da[e] * rbf(g * sg);                            // d up = dact · bf16(silu(gate))
+      swiglu_bwd_pair(v[2 * e], v[2 * e + 1], da[e], o[2 * e], o[2 * e + 1]);   // (d gate, d up = dact · bf16(silu(gate)))
     }
     *(u32x4_t*)(dgu + r * ldo + 2 * j) = pack8(o);
   }
@@ -327,7 +324,7 @@ __global__ void gelu_bwd_kernel(const uint16_t* x, long ldx, const uint16_t* dy,
     unpack8(*(const u32x4_t*)(dy + r * lddy + c), d);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      d[i] *= 0.5f * (1.0f + erf_as(v[i] * 0.70710678118654752440f)) + v[i] * 0.39894228040143267794f * __expf(-0.5f * v[i] * v[i]);
+      d[i] *= gelu_erf_grad(v[i]);
     *(u32x4_t*)(dx + r * lddx + c) = pack8(d);
   }
 }

@@ -16,12 +16,14 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (AttnDesc, GemmDesc, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_F32, EPI_F32_BF16R, EPI_NONE,
+from ._lib import (AttnDesc, GemmDesc, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_KEEP, EPI_BIAS_RES, EPI_F32, EPI_F32_BF16R, EPI_GELU_BWD,
+                   EPI_NONE, EPI_SWIGLU_BWD, EPI_SWIGLU_KEEP,
                    EPI_RES, EPI_SWIGLU)
 
 __all__ = ["Op", "gemm", "gemm_fp8", "quantize_rows_fp8", "quantize_weight_fp8", "pack_weight", "unpack_weight", "cross_entropy", "layernorm", "rmsnorm", "rmsnorm_skinny", "skinny_rows_supported", "attention", "attention_rope", "attention_decode", "attention_decode_rope", "attention_decode_rope_grouped", "skinny_supported", "rope_kvcache", "embed_splice",
            "argmax", "im2col_patch14", "preprocess_u8", "resample_coeffs", "resize_bicubic_u8", "resize_u8", "crop_resize_bilinear_u8", "write_prefix_tokens", "fill_synth", "run_all",
-           "EPI_NONE", "EPI_BIAS", "EPI_BIAS_GELU", "EPI_BIAS_RES", "EPI_RES", "EPI_SWIGLU", "EPI_F32", "EPI_F32_BF16R"]
+           "EPI_NONE", "EPI_BIAS", "EPI_BIAS_GELU", "EPI_BIAS_RES", "EPI_RES", "EPI_SWIGLU", "EPI_F32", "EPI_F32_BF16R",
+           "EPI_SWIGLU_KEEP", "EPI_BIAS_GELU_KEEP", "EPI_SWIGLU_BWD", "EPI_GELU_BWD"]
 
 
 def _stream() -> int:
@@ -113,9 +115,13 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, epilogue: int = EP
          out_map: Optional[Tuple[int, int, int]] = None,
          skinny: Optional[bool] = None, algo_nk: Optional[Tuple[int, int]] = None,
          a_norm: Optional[Tuple[torch.Tensor, float]] = None, workspace: Optional[torch.Tensor] = None,
-         skinny_rows: bool = False, run: bool = True) -> Op:
+         skinny_rows: bool = False, out2: Optional[torch.Tensor] = None, run: bool = True) -> Op:
     """out = epilogue(A @ W.T).  A [M,K] row-major activations; W = PACKED weight [N/16, K/32, 64, 8] (pack_weight);
-    out [rows, N] (N/2 for SWIGLU; fp32 for F32*).
+    out [rows, N] (N/2 for SWIGLU, 2N for SWIGLU_BWD; fp32 for F32*).
+
+    Training forms: EPI_SWIGLU_KEEP / EPI_BIAS_GELU_KEEP write the pre-activation to `out` and the activation to `out2`
+    ([rows, N/2] / [rows, N]); EPI_SWIGLU_BWD / EPI_GELU_BWD apply the activation's backward to the product, reading the
+    saved pre-activation through `res` ([rows, 2N] gate/up pairs / [rows, N]).
 
     `out_map=(group, stride, offset)` remaps output rows (see bl_gemm_desc).
     `skinny=None` picks the weight-streaming kernel automatically for M <= 16 when it supports K.
@@ -149,12 +155,24 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, epilogue: int = EP
     if res is not None:
         d.res, d.ldres = _bf16(res, "res").data_ptr(), _rows(res, "res"); keep.append(res)
     d.res_row_mod = res_row_mod
+    if epilogue in (EPI_SWIGLU_KEEP, EPI_BIAS_GELU_KEEP):
+        if out2 is None:
+            raise ValueError("gemm: the *_KEEP epilogues need out2")
+        n2 = N // 2 if epilogue == EPI_SWIGLU_KEEP else N
+        if out2.shape[1] < n2 or out2.shape[0] < M:
+            raise ValueError(f"gemm: out2 {tuple(out2.shape)} too small for [{M}, {n2}]")
+        d.C2, d.ldc2 = _bf16(out2, "out2").data_ptr(), _rows(out2, "out2"); keep.append(out2)
+    elif out2 is not None:
+        raise ValueError("gemm: out2 only with the *_KEEP epilogues")
+    if epilogue in (EPI_SWIGLU_BWD, EPI_GELU_BWD) and (res is None or res.shape[0] < M or
+                                                       res.shape[1] < (2 * N if epilogue == EPI_SWIGLU_BWD else N)):
+        raise ValueError("gemm: the *_BWD epilogues read the saved pre-activation through res")
     if out_map is not None:
         d.out_group, d.out_stride, d.out_offset = out_map
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
         keep.append(workspace)
-    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    n_out = N // 2 if epilogue == EPI_SWIGLU else 2 * N if epilogue == EPI_SWIGLU_BWD else N
     if out.shape[1] < n_out:
         raise ValueError(f"gemm: out has {out.shape[1]} columns, needs {n_out}")
     if out_map is None and out.shape[0] < M:

@@ -26,12 +26,20 @@ import torch
 
 from .. import ops, train_ops as T
 from ..engine import rope_tables
-from ..ops import EPI_BIAS, EPI_F32, EPI_F32_BF16R, EPI_NONE, EPI_RES, Op
+from ..ops import (EPI_BIAS, EPI_BIAS_GELU_KEEP, EPI_F32, EPI_F32_BF16R, EPI_GELU_BWD, EPI_NONE, EPI_RES, EPI_SWIGLU_BWD,
+                   EPI_SWIGLU_KEEP, Op)
 from ..weights import PackedGroup, VLAWeights, _block_view, _unpack
 from .sharding import ShardComm, ShardLayout, bucket_key, comm_order
 
 IGNORE_INDEX = -100
 WGRAD_NT = os.environ.get("BL_WGRAD_NT", "") not in ("", "0")     # A/B aid: weight gradients through transposed copies
+# SwiGLU / GELU forward ("f") and backward ("b") as GEMM epilogues (BL_EPI_*_KEEP / BL_EPI_*_BWD) instead of separate
+# elementwise passes. OFF by default — measured on one MI355X at 7B, B = 32 (round 4, same box, alternating runs): separate
+# passes 442.2 ms / step, backward fused 442.7, forward fused 446.2, both 444.5. The tile GEMM holds one workgroup per CU, so
+# its epilogue is fully exposed (the matrix pipes idle while 512 lanes store); the extra stores / exp / erf of a fused
+# activation cost more there than the HBM-bound pass they remove (which runs at 5 TB/s). Bit-identical either way.
+_FA = os.environ.get("BL_TRAIN_FUSED_ACT", "")
+UNFUSED_FWD, UNFUSED_BWD = "f" not in _FA, "b" not in _FA
 
 # stage → (vision trainable, projector trainable, llm: "all" | "last" | "none")   — prismatic.py:129-241
 STAGES: Dict[str, Tuple[bool, bool, str]] = {
@@ -750,7 +758,8 @@ class TrainStep:
         self._lora_t[packed.data_ptr()] = t
         return [self._g(x, ad.A_p, t, EPI_NONE), self._g(wide[:, :K + R], self._Wext[packed.data_ptr()], out, epilogue, **kw)]
 
-    def _lin_bwd(self, dy: torch.Tensor, x: torch.Tensor, packed: torch.Tensor, dx: Optional[torch.Tensor]) -> List[Op]:
+    def _lin_bwd(self, dy: torch.Tensor, x: torch.Tensor, packed: torch.Tensor, dx: Optional[torch.Tensor],
+                 epilogue: int = EPI_NONE, **kw) -> List[Op]:
         """Backward of one nn.Linear given dy: base wgrad (if trainable) and dx = dy·W (if wanted); with an adapter:
         dt = dy·(sB) into the spare columns of dy's buffer, dB = (s·tᵀ·dy)ᵀ and dA = dtᵀ·x through the small-output TN
         GEMM (dy / x read once, untransposed), and dx = [dy | dt]·[Wᵀ | Aᵀ]ᵀ as ONE GEMM."""
@@ -763,7 +772,7 @@ class TrainStep:
                 plan += [ops.quantize_rows_fp8(dy, q, self._sdy, run=False)[2],
                          ops.gemm_fp8(q, self._sdy, e8["wT8"], e8["swT"], dx, EPI_NONE, run=False)]
             elif dx is not None:
-                plan.append(self._dgrad(dy, packed, dx))
+                plan.append(self._dgrad(dy, packed, dx, epilogue, **kw))
             return plan
         i, st, s, R, N = ad.index, self.store, self.lora.scaling, ad.R, dy.shape[1]
         key = packed.data_ptr()
@@ -778,8 +787,32 @@ class TrainStep:
             plan.append(T.lora_block_mask(gB, R // len(ad.modules), len(ad.modules), ad.mode == "interleave", run=False))
         plan.append(T.gemm_tn_small(dt, x, gA, False, self.tn_ws, run=False))
         if dx is not None:
-            plan.append(self._g(wide[:, :N + R], self._WText[key], dx, EPI_NONE))
+            plan.append(self._g(wide[:, :N + R], self._WText[key], dx, epilogue, **kw))
         return plan
+
+    def _lin_act(self, x, packed, pre, act, kind: str, **kw) -> List[Op]:
+        """Linear + activation of the training forward with the PRE-activation kept (autograd's saved tensor): one GEMM
+        whose epilogue writes both (`kind` "swiglu": gate/up interleaved → silu(g)·u; "gelu": bias + exact-erf GELU). The
+        e4m3 path and the default (BL_TRAIN_FUSED_ACT unset, see above) keep the plain epilogue + an elementwise pass; both forms
+        give the same bits."""
+        fused = not UNFUSED_FWD and self._w8.get(packed.data_ptr()) is None
+        if kind == "swiglu":
+            if fused:
+                return self._lin(x, packed, pre, EPI_SWIGLU_KEEP, out2=act, **kw)
+            return self._lin(x, packed, pre, EPI_NONE, **kw) + [T.swiglu(pre, act, run=False)]
+        if fused:
+            return self._lin(x, packed, pre, EPI_BIAS_GELU_KEEP, out2=act, **kw)
+        return self._lin(x, packed, pre, EPI_BIAS, **kw) + [T.gelu(pre, act, run=False)]
+
+    def _lin_bwd_act(self, dy, x, packed, pre, dpre, dact, kind: str) -> List[Op]:
+        """Backward of `act(pre)` → Linear(packed) given dy of the linear: the input-gradient GEMM's epilogue applies the
+        activation's backward with the saved pre-activation, so d act never travels through HBM (dact is only used by the
+        unfused forms: e4m3 dgrad and the default)."""
+        fused = not UNFUSED_BWD and self._w8.get(packed.data_ptr()) is None
+        if not fused:
+            bwd = T.swiglu_backward(pre, dact, dpre, run=False) if kind == "swiglu" else T.gelu_backward(pre, dact, dpre, run=False)
+            return self._lin_bwd(dy, x, packed, dact) + [bwd]
+        return self._lin_bwd(dy, x, packed, dpre, epilogue=EPI_SWIGLU_BWD if kind == "swiglu" else EPI_GELU_BWD, res=pre)
 
     def _gvec(self, name: str, n: int) -> torch.Tensor:
         """fp32 gradient slot of a vector parameter, or a scratch sink when it is frozen."""
@@ -797,8 +830,8 @@ class TrainStep:
         plan: List[Op] = []
         # projector with the pre-activations kept (modeling_prismatic.py:151-156)
         lin = self._lin
-        plan += lin(self.feats, w.fc1_w, self.z1, EPI_BIAS, bias=w.fc1_b) + [T.gelu(self.z1, self.p1, run=False)]
-        plan += lin(self.p1, w.fc2_w, self.z2, EPI_BIAS, bias=w.fc2_b) + [T.gelu(self.z2, self.p2, run=False)]
+        plan += self._lin_act(self.feats, w.fc1_w, self.z1, self.p1, "gelu", bias=w.fc1_b)
+        plan += self._lin_act(self.p1, w.fc2_w, self.z2, self.p2, "gelu", bias=w.fc2_b)
         plan += lin(self.p2, w.fc3_w, self.p3, EPI_BIAS, bias=w.fc3_b)
         plan += [T.map_rows(self.p3, self.x[0], rows=B * 256, group=256, stride=S, offset=1, scatter=True, run=False),
                  ops.embed_splice(self.input_ids, w.embed, self.x[0].view(B, S, D), d.n_patches, run=False)]
@@ -833,8 +866,8 @@ class TrainStep:
                                  head_dim=hd, q_strides=st, k_strides=st, v_strides=st, o_strides=so,
                                  causal=True, key_mask=self.key_mask, run=False)]
         plan += lin(self.ao[l], lw.o_w, xm, EPI_RES, res=x)
-        plan += [ops.rmsnorm(xm, lw.ln2, self.h2[l], d.rms_eps, run=False)] + lin(self.h2[l], lw.gu_w, self.gu[l], EPI_NONE)
-        plan += [T.swiglu(self.gu[l], self.act[l], run=False)]
+        plan += [ops.rmsnorm(xm, lw.ln2, self.h2[l], d.rms_eps, run=False)]
+        plan += self._lin_act(self.h2[l], lw.gu_w, self.gu[l], self.act[l], "swiglu")
         if with_down:
             plan += lin(self.act[l], lw.down_w, self.x[l + 1], EPI_RES, res=xm)
         return plan
@@ -867,8 +900,7 @@ class TrainStep:
                 plan.append(self._await_grad_slot_ops(l))
             if self.recompute:         # incl. the top layer: the plan stays idempotent (graph capture runs it twice)
                 plan += self._layer_forward(l, with_down=False)
-            plan += lb(dx, self.act[l], lw.down_w, self.dact)
-            plan.append(T.swiglu_backward(self.gu[l], self.dact, self.dgu, run=False))
+            plan += self._lin_bwd_act(dx, self.act[l], lw.down_w, self.gu[l], self.dgu, self.dact, "swiglu")
             plan += lb(self.dgu, self.h2[l], lw.gu_w, self.dh)
             plan.append(T.rmsnorm_backward(self.xm[l], lw.ln2, self.dh, dx2, self._gvec(f"{b}.post_attention_layernorm.weight", D),
                                            self.norm_ws, d.rms_eps, dres=dx, run=False))
@@ -897,11 +929,9 @@ class TrainStep:
         if st.trainable("projector.fc3.weight") or self.lora is not None:
             plan.append(T.map_rows(dx, self.dp3, rows=B * 256, group=256, stride=S, offset=1, scatter=False, run=False))
             plan += self._bias_grad(self.dp3, "projector.fc3.bias")
-            plan += lb(self.dp3, self.p2, w.fc3_w, self.dp2)
-            plan.append(T.gelu_backward(self.z2, self.dp2, self.dz2, run=False))
+            plan += self._lin_bwd_act(self.dp3, self.p2, w.fc3_w, self.z2, self.dz2, self.dp2, "gelu")
             plan += self._bias_grad(self.dz2, "projector.fc2.bias")
-            plan += lb(self.dz2, self.p1, w.fc2_w, self.dp1)
-            plan.append(T.gelu_backward(self.z1, self.dp1, self.dz1, run=False))
+            plan += self._lin_bwd_act(self.dz2, self.p1, w.fc2_w, self.z1, self.dz1, self.dp1, "gelu")
             plan += self._bias_grad(self.dz1, "projector.fc1.bias")
             plan += lb(self.dz1, self.feats, w.fc1_w, self.dfeats if self.train_vision else None)
             self._ready.append((len(plan), "projector"))
@@ -955,8 +985,7 @@ class TrainStep:
             else:
                 plan += self._lin(sv["ao"][i], b.proj_w, xm, ops.EPI_BIAS_RES, bias=b.proj_b, res=x)
             plan.append(ops.layernorm(xm, b.norm2_w, b.norm2_b, sv["h2"][i], eps, run=False))
-            plan += self._lin(sv["h2"][i], b.fc1_w, sv["zz"][i], EPI_BIAS, bias=b.fc1_b)
-            plan.append(T.gelu(sv["zz"][i], sv["f"][i], run=False))
+            plan += self._lin_act(sv["h2"][i], b.fc1_w, sv["zz"][i], sv["f"][i], "gelu", bias=b.fc1_b)
             if b.ls2 is not None:
                 plan += self._lin(sv["f"][i], b.fc2_w, sv["u2"][i], EPI_BIAS, bias=b.fc2_b)
                 plan.append(T.scale_residual(sv["u2"][i], b.ls2, xm, sv["x"][i + 1], run=False))
@@ -990,8 +1019,7 @@ class TrainStep:
                 plan.append(T.layerscale_backward(dx, sv["u2"][i], b.ls2, sv["du"], gv(f"{bn}.ls2.scale_factor"), self.col_ws, run=False))
                 dbr = sv["du"]
             plan += self._bias_grad(dbr, f"{bn}.mlp.fc2.bias")
-            plan += lb(dbr, sv["f"][i], b.fc2_w, sv["df"])
-            plan.append(T.gelu_backward(sv["zz"][i], sv["df"], sv["dz"], run=False))
+            plan += self._lin_bwd_act(dbr, sv["f"][i], b.fc2_w, sv["zz"][i], sv["dz"], sv["df"], "gelu")
             plan += self._bias_grad(sv["dz"][:, :t.mlp], f"{bn}.mlp.fc1.bias")
             plan += lb(sv["dz"], sv["h2"][i], b.fc1_w, sv["dh"])
             plan.append(T.layernorm_backward(sv["xm"][i], b.norm2_w, sv["dh"], dx2, gv(f"{bn}.norm2.weight"), gb(f"{bn}.norm2.bias"),

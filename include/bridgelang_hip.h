@@ -65,7 +65,16 @@ enum bl_epilogue {
   BL_EPI_RES = 4,         /* t = bf16(acc);            C = bf16(res + t)                                */
   BL_EPI_SWIGLU = 5,      /* W rows interleaved (2j = gate_j, 2j+1 = up_j); C[m, j] = silu(g)*u, N/2 wide */
   BL_EPI_F32 = 6,         /* C = acc  (fp32 output)                                                     */
-  BL_EPI_F32_BF16R = 7    /* C = (float)bf16(acc): HF `lm_head(h).float()` — logits are bf16 values upcast     */
+  BL_EPI_F32_BF16R = 7,   /* C = (float)bf16(acc): HF `lm_head(h).float()` — logits are bf16 values upcast     */
+  /* Training-step forms (bl_gemm_bf16 only; what autograd keeps / computes around the same nn.Linear under
+   * `loss.backward()`, prismatic/training/strategies/base_strategy.py:296-302). The *_KEEP forms write the pre-activation
+   * to C (autograd's saved tensor) AND the activation to C2; the *_BWD forms apply the activation's backward to the
+   * input-gradient GEMM's result, reading the saved pre-activation through `res`. Bit-identical to the plain epilogue
+   * followed by bl_swiglu_bf16 / bl_gelu_bf16 / bl_swiglu_backward_bf16 / bl_gelu_backward_bf16. */
+  BL_EPI_SWIGLU_KEEP = 8,     /* C[m, n] = bf16(acc) (gate/up interleaved, N wide); C2[m, j] = silu(g)*u (N/2 wide)  */
+  BL_EPI_BIAS_GELU_KEEP = 9,  /* C = t = bf16(acc + bias[n]);  C2 = bf16(gelu_erf(t))                                */
+  BL_EPI_SWIGLU_BWD = 10,     /* d = bf16(acc) = dL/d act[m, n];  res = saved gate/up [m, 2n..]; C[m, 2n..2n+1] = (d gate, d up) — C is 2N wide */
+  BL_EPI_GELU_BWD = 11        /* d = bf16(acc) = dL/d gelu(t)[m, n];  res = saved t;  C = bf16(d * gelu'(t))          */
 };
 
 typedef struct bl_gemm_desc {
@@ -93,6 +102,9 @@ typedef struct bl_gemm_desc {
    * undefined after the call; calls that share a workspace must be ordered on one stream. */
   void* workspace;
   int64_t workspace_bytes;
+  /* second output of the BL_EPI_*_KEEP epilogues (bf16); NULL otherwise */
+  bl_bf16* C2;
+  int64_t ldc2;
 } bl_gemm_desc;
 
 int bl_gemm_bf16(const bl_gemm_desc* d, void* stream);

@@ -319,3 +319,38 @@ def test_pack_into_windows(dev):
     T.transpose_pack_into(dv(w, dev), WTe, n, NT, 0)
     T.transpose_pack_into(dv(a, dev), WTe, R, NT, n // 32)
     assert torch.equal(WTe, ops.pack_weight(dv(torch.cat([w.t(), a.t()], 1).contiguous(), dev)))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (9472 // 8, 1024, 512), (70, 64, 192)])
+def test_training_epilogues_equal_the_two_kernel_forms(dev, M, N, K):
+    """The training-step GEMM epilogues (BL_EPI_SWIGLU_KEEP / BIAS_GELU_KEEP / SWIGLU_BWD / GELU_BWD) must reproduce, bit for
+    bit, the plain epilogue followed by the elementwise kernel they replace (bl_swiglu_bf16, bl_gelu_bf16,
+    bl_swiglu_backward_bf16, bl_gelu_backward_bf16 — each checked against autograd above)."""
+    from bridgelang_amd import ops, train_ops as T
+    x, w, bias = dv(rand_bf16((M, K), 1), dev), rand_bf16((N, K), 2, 0.1), dv(rand_bf16((N,), 3), dev)
+    wp = ops.pack_weight(dv(w, dev))
+    bits = lambda t: t.view(torch.int16)
+    z = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=dev)
+    # forward, SwiGLU: rows of W interleave gate / up
+    pre_a, act_a, pre_b, act_b = z(M, N), z(M, N // 2), z(M, N), z(M, N // 2)
+    ops.gemm(x, wp, pre_a, ops.EPI_NONE); T.swiglu(pre_a, act_a)
+    ops.gemm(x, wp, pre_b, ops.EPI_SWIGLU_KEEP, out2=act_b)
+    assert torch.equal(bits(pre_a), bits(pre_b)) and torch.equal(bits(act_a), bits(act_b))
+    only = z(M, N // 2)
+    ops.gemm(x, wp, only, ops.EPI_SWIGLU)                           # the inference epilogue: same activation
+    assert torch.equal(bits(only), bits(act_b))
+    # forward, bias + GELU
+    g_a, g_b, t_b = z(M, N), z(M, N), z(M, N)
+    ops.gemm(x, wp, pre_a, ops.EPI_BIAS, bias=bias); T.gelu(pre_a, g_a)
+    ops.gemm(x, wp, t_b, ops.EPI_BIAS_GELU_KEEP, bias=bias, out2=g_b)
+    assert torch.equal(bits(pre_a), bits(t_b)) and torch.equal(bits(g_a), bits(g_b))
+    # backward: dy [M, K'] · Wt → d act [M, N'] with the saved pre-activation
+    saved_gu, saved_t = dv(rand_bf16((M, 2 * N), 5, 2.0), dev), dv(rand_bf16((M, N), 6, 2.0), dev)
+    d_act, dgu_a, dgu_b = z(M, N), z(M, 2 * N), z(M, 2 * N)
+    ops.gemm(x, wp, d_act, ops.EPI_NONE); T.swiglu_backward(saved_gu, d_act, dgu_a)
+    ops.gemm(x, wp, dgu_b, ops.EPI_SWIGLU_BWD, res=saved_gu)
+    assert torch.equal(bits(dgu_a), bits(dgu_b)) and dgu_b.float().abs().max() > 0
+    dt_a, dt_b = z(M, N), z(M, N)
+    T.gelu_backward(saved_t, d_act, dt_a)
+    ops.gemm(x, wp, dt_b, ops.EPI_GELU_BWD, res=saved_t)
+    assert torch.equal(bits(dt_a), bits(dt_b)) and dt_b.float().abs().max() > 0
