@@ -76,6 +76,22 @@ def trainable_names(w: VLAWeights, stage: str) -> List[str]:
     return out
 
 
+def pl_is_plain(w: VLAWeights, name: str) -> bool:
+    return w.placements[name].group is None
+
+
+# buckets whose PARAMETERS are sharded under fsdp-full-shard: every FSDP unit of the reference — decoder layers, ViT blocks
+# (+ patch embeddings), projector, and the root's token embeddings / lm_head (prismatic.py:285-306, dinosiglip_vit.py:136-140,
+# base_llm.py:182-188, fsdp.py:160-168). Not sharded: the two buckets of small plain tensors.
+def param_sharded_key(key: str) -> bool:
+    return key.startswith(("llm.layer", "vision.", "projector", "llm.lm_head", "llm.embed"))
+
+
+def pool_of(key: str) -> str:
+    """Gather-slot pool of a parameter-sharded bucket: uniform decoder layers / the vision units / the three big singletons."""
+    return "layers" if key.startswith("llm.layer") else "vision" if key.startswith("vision.") else "head"
+
+
 def no_decay(name: str, shape: Tuple[int, ...]) -> bool:
     """fsdp.py:208: `param.ndim <= 1 or name.endswith(".bias")` → weight_decay 0."""
     return len(shape) <= 1 or name.endswith(".bias")
@@ -134,12 +150,20 @@ class ParamStore:
             self.units.append(u)
             for n in g.members:
                 self.by_name[n] = u
-        for decay in (True, False):                             # plain tensors: one bucket per weight-decay class
-            todo = [(n, pl) for n, pl in w.placements.items() if pl.group is None and n in names
-                    and (not no_decay(n, specs[n].shape)) == decay]
+        EMBED = "language_model.model.embed_tokens.weight"
+        # (bucket key, decayed, names): the token embeddings are half of the reference's root FSDP unit (fsdp.py:160-168) and get
+        # a bucket of their own right behind the GEMM-weight buckets (parameter-sharded with them); the other plain tensors
+        # (norm scales, biases, LayerScale, position / class tokens: 0.1 % of the model) share one bucket per weight-decay class
+        plain_buckets = [("llm.embed", True, [EMBED])] if EMBED in names and pl_is_plain(w, EMBED) else []
+        for decay in (True, False):
+            plain_buckets.append(("plain.decay" if decay else "plain.nodecay", decay,
+                                  [n for n, pl in w.placements.items() if pl.group is None and n in names and n != EMBED
+                                   and (not no_decay(n, specs[n].shape)) == decay]))
+        for bkey, decay, members in plain_buckets:
+            todo = [(n, w.placements[n]) for n in members]
             if not todo:
                 continue
-            lay.begin("plain.decay" if decay else "plain.nodecay", decay)
+            lay.begin(bkey, decay)
             for name, pl in todo:
                 assert pl.ld == pl.cols or pl.rows == 1
                 dst = pl.dst.view(-1)[pl.offset:pl.offset + pl.rows * pl.cols]
@@ -168,20 +192,30 @@ class ParamStore:
         # one of two slots (`gslots`) between that layer's weight-gradient GEMMs and its reduce-scatter, as FSDP frees a
         # unit's full gradient after reduce-scatter (fsdp.py:160-168).
         self.shard_params = shard_params
-        sh = [b for b in lay.buckets if shard_params and b.key.startswith("llm.layer")]
+        sh = [b for b in lay.buckets if shard_params and param_sharded_key(b.key)]
         self.sharded_keys = {b.key for b in sh}
         self._cut = (sh[0].offset, sh[-1].offset + sh[-1].numel) if sh else (lay.total, lay.total)
         assert sum(b.numel for b in sh) == self._cut[1] - self._cut[0], "parameter-sharded buckets must be contiguous"
         self._n_rep = n_rep = lay.total - (self._cut[1] - self._cut[0])
         self.stage_bf16 = torch.zeros(max(n_rep, 8), dtype=torch.bfloat16, device=dev)
         self.own_off, n_own = {}, 0
+        # gradient slots: per pool two transient fp32 buffers sized for the pool's largest bucket; a bucket uses slot
+        # (its index in the pool's forward order) % 2 — for the decoder layers that is layer % 2
+        self.grad_slot_of: Dict[str, Tuple[str, int]] = {}
+        self._slot_numel: Dict[str, int] = {}
+        seen: Dict[str, int] = {}
         for b in sh:
             self.own_off[b.key] = n_own
             n_own += lay.shard_numel(b)
-        self._n_own, self._slot_numel = n_own, max((b.numel for b in sh), default=0)
+            pool = pool_of(b.key)
+            idx = int(b.key[len("llm.layer"):]) if pool == "layers" else seen.get(pool, 0)
+            seen[pool] = seen.get(pool, 0) + 1
+            self.grad_slot_of[b.key] = (pool, idx % 2)
+            self._slot_numel[pool] = max(self._slot_numel.get(pool, 0), b.numel)
+        self._n_own = n_own
         self.own = torch.zeros(max(n_own, 8), dtype=torch.bfloat16, device=dev) if sh else None
         self.grad = self.gshard = None
-        self.gslots: List[torch.Tensor] = []
+        self.gslots: Dict[str, List[torch.Tensor]] = {}
         self.use_grad_slots = True          # TrainStep clears it when no collective runs (world 1): the "slice" is then the whole
                                             # bucket and the weight-gradient GEMMs write the persistent buffer directly
         if not defer_grads:                 # TrainStep defers: it first gives the model's own decoder-layer allocation back
@@ -218,7 +252,8 @@ class ParamStore:
         if self.sharded_keys:
             self.gshard = torch.zeros(max(self._n_own, 8), dtype=torch.float32, device=dev)
             if self.use_grad_slots:
-                self.gslots = [torch.zeros(self._slot_numel, dtype=torch.float32, device=dev) for _ in range(2)]
+                self.gslots = {pool: [torch.zeros(n, dtype=torch.float32, device=dev) for _ in range(2)]
+                               for pool, n in self._slot_numel.items()}
 
     # ---- views ----
     def _replicated(self, buf: torch.Tensor, offset: int, numel: int) -> torch.Tensor:
@@ -242,11 +277,13 @@ class ParamStore:
         return self.own[o:o + self.layout.shard_numel(b)]
 
     def grad_slot(self, b) -> torch.Tensor:
-        """The transient full-size fp32 gradient of parameter-sharded bucket b (decoder layer l uses slot l % 2)."""
+        """The transient full-size fp32 gradient of parameter-sharded bucket b (decoder layer l uses slot l % 2 of the
+        layer pool; the vision / head units alternate inside their pools)."""
         if not self.use_grad_slots:          # one rank, no collective: the rank's slice of the reduced gradient is the bucket itself
             assert self.layout.world == 1
             return self.reduced_grad(b)
-        return self.gslots[int(b.key[len("llm.layer"):]) % 2][:b.numel]
+        pool, parity = self.grad_slot_of[b.key]
+        return self.gslots[pool][parity][:b.numel]
 
     def reduced_grad(self, b) -> torch.Tensor:
         """This rank's slice of bucket b's gradient once reduced: what the norm and AdamW read."""
@@ -370,9 +407,12 @@ class TrainStep:
         self._wT: Dict[int, torch.Tensor] = {}       # transposed packed weights for dgrad
         self._w8: Dict[int, dict] = {}              # packed bf16 weight (data_ptr) → its e4m3 forward / dgrad copies + scales
         self._cur_layer = -1                   # decoder layer whose ops are being planned (slot tensors are shared by layers)
+        self._cur_unit: Optional[str] = None   # vision / head unit (bucket key) whose ops are being planned
+        self._units: Dict[str, dict] = {}      # parameter-sharded vision / head units (see _setup_unit_pools)
         self._materialized = False
         if shard_params:                       # first: the model's layer allocation is given back before anything else is reserved
             self._setup_param_shards()
+            self._setup_unit_pools()
         if st.grad is None:
             st.use_grad_slots = self.comm.active
         st.alloc_grads()
@@ -403,6 +443,8 @@ class TrainStep:
         #      prompt_len 1, no decode) ----
         from ..engine import OpenVLAEngine
         self._vis = OpenVLAEngine(weights, batch, 1, n_new=1, vision_only=True)
+        if any(info["pool"] == "vision" for info in self._units.values()):
+            self._vis.dino_ops = self._vis.siglip_ops = self._vis.vision_ops = []      # the towers' weights live in gather slots
         self.pixel_values = self._vis.pixel_values
         self.feats = self._vis.feats if lora is None else za(B * 256, d.vision_dim, R_(weights.fc1_w))
         # ---- saved activations ----
@@ -459,6 +501,11 @@ class TrainStep:
             self._setup_fp8()
         if lora is not None:
             self._build_extended_weights()
+        # execution order of the vision units (forward; the backward visits each tower's blocks top down, then its stem)
+        vkey = lambda tw, i: f"vision.{tw.dims.prefix.split('.')[1]}." + ("stem" if i < 0 else f"block{i:02d}")
+        self._vkey = vkey
+        self._vseq_fwd = [vkey(tw, i) for tw in towers for i in range(-1, tw.dims.n_run)]
+        self._vseq_bwd = [vkey(tw, i) for tw in towers for i in list(range(tw.dims.n_run - 1, -1, -1)) + [-1]]
         self.vision_forward_ops: List[Op] = []
         for tw, sv, col in zip(towers, self.vis, (0, d.dino.dim)):
             self.vision_forward_ops += self._plan_tower_forward(tw, col, sv)
@@ -469,8 +516,8 @@ class TrainStep:
         self.repack_ops = self._plan_repack()
         self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
         self._comm_stream = torch.cuda.Stream(device=dev) if (self.comm.active or shard_params) else None
-        self._rs_scratch = (z(self._slots[0]["flat"].numel()) if shard_params and self.comm.active
-                            and reduce_dtype != torch.float32 else None)        # bf16 wire copy of one layer's gradients
+        self._rs_scratch = (z(max(st._slot_numel.values())) if shard_params and self.comm.active
+                            and reduce_dtype != torch.float32 else None)        # bf16 wire copy of one unit's gradients
 
     # ---- helpers ------------------------------------------------------------------------------------------------
     # ---- fp8 (e4m3) forward / dgrad GEMMs of the decoder layers ------------------------------------------------------
@@ -590,6 +637,139 @@ class TrainStep:
                 bwd.append(T.transpose_pack(rm, slot[key + "T"], u.group.n, run=False))   # dgrad operand layout
             self._pack_ops[l] = (fwd, bwd + fwd if self.recompute else bwd)
 
+
+    # ---- the other FSDP units: ViT blocks + patch embeddings ("vision" pool), projector / token embeddings / lm_head ("head") ----
+    def _setup_unit_pools(self) -> None:
+        """Same machinery as the decoder layers for the reference's remaining FSDP units (prismatic.py:285-306,
+        dinosiglip_vit.py:136-140, fsdp.py:160-168): per pool TWO gather slots — the logical bf16 bucket + one buffer of
+        forward layouts + one of dgrad layouts, each sized for the pool's largest unit and carved into per-unit views — the
+        model's tensors are re-pointed at the views of slot (unit index % 2) and the pool's own allocation is freed. A unit is
+        all-gathered (and packed) into its slot one unit ahead of its use, on the communication stream; its weight gradients
+        go to one of two transient fp32 slots of the pool and are reduce-scattered into the rank's persistent slice right
+        after the unit's last weight-gradient GEMM. The token embeddings are a plain [vocab, D] tensor: read in place from the
+        gathered bucket."""
+        w, st, lay, dev = self.w, self.store, self.store.layout, self.device
+        by_group = {id(u.group): u for u in st.units if u.group is not None}
+        by_key = {b.key: b for b in lay.buckets}
+        self._pool_slots: Dict[str, List[dict]] = {}
+        for pool in ("vision", "head"):
+            fields = w.unit_fields(pool)                                   # (unit key, path, group index | None, HF name | None)
+            keys = list(dict.fromkeys(k for k, *_ in fields))
+            live = [k for k in keys if k in st.sharded_keys]
+            if not live:
+                continue
+            if len(live) != len(keys):
+                raise ValueError(f"parameter sharding needs every unit of the {pool} pool trainable or none ({set(keys) - set(live)} frozen)")
+            numel = lambda k: sum(w.groups[gi].n * w.groups[gi].k for kk, _, gi, _ in fields if kk == k and gi is not None)
+            flat_max, pk_max = max(by_key[k].numel for k in keys), max(max(numel(k) for k in keys), 8)
+            slots = [dict(flat=torch.zeros(flat_max, dtype=torch.bfloat16, device=dev),
+                          fwd=torch.zeros(pk_max, dtype=torch.bfloat16, device=dev),
+                          bwd=torch.zeros(pk_max, dtype=torch.bfloat16, device=dev),
+                          ready=torch.cuda.Event(), free=torch.cuda.Event(), grads_flushed=torch.cuda.Event()) for _ in range(2)]
+            self._pool_slots[pool] = slots
+            views: Dict[tuple, torch.Tensor] = {}
+            for k in keys:
+                b = by_key[k]
+                parity = st.grad_slot_of[k][1]
+                slot, off = slots[parity], 0
+                info = dict(pool=pool, parity=parity, bucket=b, by_ptr={}, T={}, fwd_ops=[], bwd_ops=[], plain=[])
+                for kk, path, gi, name in fields:
+                    if kk != k:
+                        continue
+                    if gi is not None:
+                        u = by_group[id(w.groups[gi])]
+                        n, kd = u.group.n, u.group.k
+                        fv = slot["fwd"][off:off + n * kd].view(n // 16, kd // 32, 64, 8)
+                        tv = slot["bwd"][off:off + n * kd].view(kd // 16, n // 32, 64, 8)
+                        off += n * kd
+                        rm = slot["flat"][u.offset - b.offset:u.offset - b.offset + u.numel].view(n, kd)
+                        info["fwd_ops"].append(T.pack(rm, fv, run=False))
+                        info["bwd_ops"].append(T.transpose_pack(rm, tv, n, run=False))
+                        info["by_ptr"][fv.data_ptr()], info["T"][fv.data_ptr()] = u, tv
+                        views[(k, path)] = fv
+                    else:                                                  # token embeddings: used where the gather lands them
+                        u = st.by_name[name]
+                        obj, attr = w._attr_of(path)
+                        views[(k, path)] = slot["flat"][u.offset - b.offset:u.offset - b.offset + u.numel].view(getattr(obj, attr).shape)
+                        info["plain"].append((path, u))
+                        u.dst = None                                       # the optimizer writes the rank's slice, nothing is copied back
+                self._units[k] = info
+            if w.pool_resident(pool):
+                w.release_unit_weights(pool, views)
+            else:                                  # re-planned step over an already sharded model
+                w.repoint_unit_weights(pool, views)
+
+    def _u_slot(self, key: str) -> dict:
+        info = self._units[key]
+        return self._pool_slots[info["pool"]][info["parity"]]
+
+    def _u_gather(self, key: str, backward: bool = False, both: bool = False) -> Op:
+        """Issue unit `key`'s parameter gather + packing (forward layouts, dgrad layouts, or both) on the communication stream."""
+        def fn():
+            info, slot, side = self._units[key], self._u_slot(key), self._comm_stream
+            side.wait_event(slot["free"])                     # the unit that used this slot before is done with it
+            with torch.cuda.stream(side):
+                b = info["bucket"]
+                self.comm.all_gather_into(slot["flat"][:b.numel], self.store.own_slice(b))
+                if both or not backward:
+                    ops.run_all(info["fwd_ops"])
+                if both or backward:
+                    ops.run_all(info["bwd_ops"])
+                slot["ready"].record(side)
+        return ops.glue("gather_unit_params", fn, ())
+
+    def _u_await(self, key: str) -> Op:
+        return ops.glue("await_unit_params", lambda: torch.cuda.current_stream().wait_event(self._u_slot(key)["ready"]), ())
+
+    def _u_release(self, key: str) -> Op:
+        return ops.glue("release_unit_params", lambda: self._u_slot(key)["free"].record(torch.cuda.current_stream()), ())
+
+    def _u_await_grad(self, key: str) -> Op:
+        return ops.glue("await_unit_grad_slot", lambda: torch.cuda.current_stream().wait_event(self._u_slot(key)["grads_flushed"]), ())
+
+    def _u_flush(self, key: str) -> Op:
+        """After the unit's last weight gradient: reduce-scatter its transient fp32 slot, keep this rank's slice."""
+        def fn():
+            st, lay, side = self.store, self.store.layout, self._comm_stream
+            if not st.use_grad_slots:
+                return
+            b = self._units[key]["bucket"]
+            gs = st.grad_slot(b)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                scratch = self._rs_scratch[:b.numel] if self._rs_scratch is not None else None
+                self.comm.reduce_scatter_bucket(gs, b, scratch)
+                n = lay.shard_numel(b)
+                T.copy_f32(gs[lay.rank * n:(lay.rank + 1) * n], st.reduced_grad(b))
+                self._u_slot(key)["grads_flushed"].record(side)
+        return ops.glue("flush_unit_grads", fn, ())
+
+    def _u_seq(self, seq: List[str], j: int, backward: bool, body: List[Op], gather: bool = True, flush: bool = True) -> List[Op]:
+        """Ops of unit seq[j] wrapped in its parameter / gradient-slot protocol: wait for its gather, start the next unit's
+        gather (after this unit's release when both share a slot), and in the backward pass wait for the gradient slot and
+        flush it afterwards. Units that are not parameter-sharded pass through."""
+        key = seq[j]
+        if key not in self._units:
+            return body
+        nxt = seq[j + 1] if j + 1 < len(seq) and seq[j + 1] in self._units else None
+        same = nxt is not None and self._u_slot(nxt) is self._u_slot(key)
+        pre: List[Op] = []
+        if j == 0 and gather:
+            pre.append(self._u_gather(key, backward))
+        pre.append(self._u_await(key))
+        if nxt is not None and not same:
+            pre.append(self._u_gather(nxt, backward))
+        if backward:
+            pre.append(self._u_await_grad(key))
+        post = [self._u_release(key)]
+        if backward and flush:
+            post.append(self._u_flush(key))
+        if nxt is not None and same:
+            post.append(self._u_gather(nxt, backward))
+        return pre + body + post
+
     def _layer_bucket(self, l: int):
         return self.store.layout.buckets[self._layer_units[(l, "qkv_w")].bucket]
 
@@ -640,6 +820,8 @@ class TrainStep:
         return ops.glue("flush_layer_grads", fn, ())
 
     def _unit_of(self, packed: torch.Tensor) -> Optional[Unit]:
+        if self._cur_unit is not None and packed.data_ptr() in self._units[self._cur_unit]["by_ptr"]:
+            return self._units[self._cur_unit]["by_ptr"][packed.data_ptr()]     # slot views are shared by the units of a pool
         if self.shard_params and packed.data_ptr() in self._slot_key:
             assert self._cur_layer >= 0, "slot weights are only addressed while a decoder layer is being planned"
             return self._layer_units[(self._cur_layer, self._slot_key[packed.data_ptr()])]
@@ -662,6 +844,21 @@ class TrainStep:
                 u = self._layer_units[(l, key)]
                 rm = slot["flat"][u.offset - b.offset:u.offset - b.offset + u.numel].view(u.group.n, u.group.k)
                 T.pack(rm, getattr(w.layers[l], key))
+        for pool, slots in getattr(self, "_pool_slots", {}).items():
+            w.restore_unit_weights(pool)
+            by_group = {id(u.group): u for u in st.units if u.group is not None}
+            for key, path, gi, name in w.unit_fields(pool):
+                info = self._units[key]
+                b, slot = info["bucket"], slots[info["parity"]]
+                torch.cuda.synchronize()                    # a slot is re-used by the next unit of its parity
+                self.comm.all_gather_into(slot["flat"][:b.numel], st.own_slice(b))
+                obj, attr = w._attr_of(path)
+                u = by_group[id(w.groups[gi])] if gi is not None else st.by_name[name]
+                rm = slot["flat"][u.offset - b.offset:u.offset - b.offset + u.numel]
+                if gi is not None:
+                    T.pack(rm.view(u.group.n, u.group.k), getattr(obj, attr))
+                else:
+                    getattr(obj, attr).view(-1).copy_(rm)
         torch.cuda.synchronize()
         self._materialized = True
 
@@ -673,6 +870,9 @@ class TrainStep:
     def wT(self, packed: torch.Tensor) -> torch.Tensor:
         """[K, N]-packed transposed copy of a packed [N, K] weight (built on first use, refreshed by repack)."""
         key = packed.data_ptr()
+        if self._cur_unit is not None and key in self._units[self._cur_unit]["T"]:
+            return self._units[self._cur_unit]["T"][key]
+        assert not any(key in info["T"] for info in self._units.values()), "slot weights are addressed while their unit is planned"
         if key not in self._wT:
             n, k = packed.shape[0] * 16, packed.shape[1] * 32
             self._wT[key] = transposed_pack(packed, n, k)
@@ -828,13 +1028,23 @@ class TrainStep:
         D, H, hd = d.llm_dim, d.llm_heads, d.head_dim
         g = self._g
         plan: List[Op] = []
+        head = "projector" in self._units          # the head pool is parameter-sharded: projector, token embeddings, lm_head
+        if head:                                   # lm_head keeps its slot (both layouts) from here to its dgrad in the backward pass
+            plan += [self._u_gather("projector"), self._u_gather("llm.lm_head", both=True), self._u_await("projector")]
         # projector with the pre-activations kept (modeling_prismatic.py:151-156)
         lin = self._lin
         plan += self._lin_act(self.feats, w.fc1_w, self.z1, self.p1, "gelu", bias=w.fc1_b)
         plan += self._lin_act(self.p1, w.fc2_w, self.z2, self.p2, "gelu", bias=w.fc2_b)
         plan += lin(self.p2, w.fc3_w, self.p3, EPI_BIAS, bias=w.fc3_b)
-        plan += [T.map_rows(self.p3, self.x[0], rows=B * 256, group=256, stride=S, offset=1, scatter=True, run=False),
-                 ops.embed_splice(self.input_ids, w.embed, self.x[0].view(B, S, D), d.n_patches, run=False)]
+        if head:                                   # the embeddings share the projector's slot: gathered once it is released
+            assert self._u_slot("llm.embed") is self._u_slot("projector") and self._u_slot("llm.lm_head") is not self._u_slot("projector")
+            plan += [self._u_release("projector"), self._u_gather("llm.embed")]
+        plan.append(T.map_rows(self.p3, self.x[0], rows=B * 256, group=256, stride=S, offset=1, scatter=True, run=False))
+        if head:
+            plan.append(self._u_await("llm.embed"))
+        plan.append(ops.embed_splice(self.input_ids, w.embed, self.x[0].view(B, S, D), d.n_patches, run=False))
+        if head:
+            plan.append(self._u_release("llm.embed"))
         NL = d.llm_layers
         if self.shard_params:
             plan.append(self._gather_ops(0))
@@ -846,6 +1056,8 @@ class TrainStep:
             plan += self._layer_forward(l)
             if self.shard_params:
                 plan.append(self._release_ops(l))
+        if head:
+            plan.append(self._u_await("llm.lm_head"))
         plan += [ops.rmsnorm(self.x[-1], w.norm, self.hn, d.rms_eps, run=False),
                  g(self.hn, w.lm_head, self.logits, EPI_F32_BF16R),
                  ops.cross_entropy(self.logits, self.targets, self.row_loss, self.mean_cnt, IGNORE_INDEX, run=False)]
@@ -877,9 +1089,16 @@ class TrainStep:
         D, H, hd = d.llm_dim, d.llm_heads, d.head_dim
         lm = "language_model.model"
         plan: List[Op] = [T.cross_entropy_backward(self.logits, self.targets, self.mean_cnt, self.dlogits, IGNORE_INDEX, run=False)]
+        head = "projector" in self._units
+        if head:
+            plan.append(self._u_await_grad("llm.lm_head"))
+            self._cur_unit = "llm.lm_head"
         plan += self._wgrad(self.dlogits, self.hn, w.lm_head)
         self._ready.append((len(plan), "llm.lm_head"))
         plan.append(self._dgrad(self.dlogits, w.lm_head, self.dh))
+        self._cur_unit = None
+        if head:                                   # the projector's dgrad layouts travel under the whole decoder backward
+            plan += [self._u_release("llm.lm_head"), self._u_flush("llm.lm_head"), self._u_gather("projector", backward=True)]
         lb = self._lin_bwd
         dx, dx2 = self.dxa, self.dxb
         plan.append(T.rmsnorm_backward(self.x[-1], w.norm, self.dh, dx, self._gvec(f"{lm}.norm.weight", D), self.norm_ws,
@@ -923,9 +1142,16 @@ class TrainStep:
             return plan
         # dx = gradient of inputs_embeds [B, S, D]
         if st.trainable(f"{lm}.embed_tokens.weight"):
+            if head:
+                plan.append(self._u_await_grad("llm.embed"))
             plan.append(T.fill_zero(st.grad_view(f"{lm}.embed_tokens.weight"), run=False))     # accumulated with atomics
             plan.append(T.embed_backward(self.input_ids, dx.view(B, S, D), st.grad_view(f"{lm}.embed_tokens.weight").view(d.vocab, D),
                                          d.n_patches, run=False))
+            if head:
+                plan.append(self._u_flush("llm.embed"))
+        if head:
+            plan += [self._u_await("projector"), self._u_await_grad("projector")]
+            self._cur_unit = "projector"
         if st.trainable("projector.fc3.weight") or self.lora is not None:
             plan.append(T.map_rows(dx, self.dp3, rows=B * 256, group=256, stride=S, offset=1, scatter=False, run=False))
             plan += self._bias_grad(self.dp3, "projector.fc3.bias")
@@ -935,6 +1161,9 @@ class TrainStep:
             plan += self._bias_grad(self.dz1, "projector.fc1.bias")
             plan += lb(self.dz1, self.feats, w.fc1_w, self.dfeats if self.train_vision else None)
             self._ready.append((len(plan), "projector"))
+            self._cur_unit = None
+            if head:
+                plan += [self._u_release("projector"), self._u_flush("projector")]
             if self.train_vision:
                 for tw, sv, col in zip((w.dino, w.siglip), self.vis, (0, d.dino.dim)):
                     plan += self._plan_tower_backward(tw, col, sv, len(plan))
@@ -965,16 +1194,21 @@ class TrainStep:
         col = self._vis.vbuf[1 if feat_col else 0]["col"]          # one im2col buffer per tower (kept for the patch wgrad)
         g = self._g
         x0 = sv["x"][0]
+        seq, j0 = self._vseq_fwd, self._vseq_fwd.index(self._vkey(tw, -1))
+        whole: List[Op] = []                       # the tower's plan; `plan` below collects one unit's ops at a time
         plan = [ops.im2col_patch14(self.pixel_values, t.chan0, col, run=False)]
         if tw.prefix is not None:
             plan.append(ops.write_prefix_tokens(tw.prefix, x0, B, Tk, run=False))
         plan.append(g(col, tw.patch_w, x0, ops.EPI_BIAS_RES, bias=tw.patch_b, res=tw.pos, res_row_mod=256,
                       out_map=(256, Tk, t.n_prefix)))
+        whole += self._u_seq(seq, j0, False, plan)
         lq, lo = sv["qkv"][0].stride(0), sv["ao"][0].stride(0)
         st, so = (Tk * lq, hd, lq), (Tk * lo, hd, lo)
         for i, b in enumerate(tw.blocks):
+            if i:
+                whole += self._u_seq(seq, j0 + i, False, plan)
             x, xm, qkv = sv["x"][i], sv["xm"][i], sv["qkv"][i]
-            plan += [ops.layernorm(x, b.norm1_w, b.norm1_b, sv["h1"][i], eps, run=False)]
+            plan = [ops.layernorm(x, b.norm1_w, b.norm1_b, sv["h1"][i], eps, run=False)]
             plan += self._lin(sv["h1"][i], b.qkv_w, qkv, EPI_BIAS, bias=b.qkv_b)
             plan += [T.attention_lse(qkv, qkv[:, Dm:], qkv[:, 2 * Dm:], sv["ao"][i], sv["lse"][i], B=B, H=t.heads, Sq=Tk,
                                      Skv=Tk, head_dim=hd, q_strides=st, k_strides=st, v_strides=st,
@@ -991,10 +1225,11 @@ class TrainStep:
                 plan.append(T.scale_residual(sv["u2"][i], b.ls2, xm, sv["x"][i + 1], run=False))
             else:
                 plan += self._lin(sv["f"][i], b.fc2_w, sv["x"][i + 1], ops.EPI_BIAS_RES, bias=b.fc2_b, res=xm)
+        whole += self._u_seq(seq, j0 + len(tw.blocks), False, plan)
         # tap: patch rows of the last block output → this tower's channels of the fused feature map
-        plan.append(T.map_rows(sv["x"][-1], self.feats[:, feat_col:feat_col + Dm], rows=B * 256, group=256, stride=Tk,
-                               offset=t.n_prefix, scatter=False, run=False))
-        return plan
+        whole.append(T.map_rows(sv["x"][-1], self.feats[:, feat_col:feat_col + Dm], rows=B * 256, group=256, stride=Tk,
+                                offset=t.n_prefix, scatter=False, run=False))
+        return whole
 
     def _plan_tower_backward(self, tw, feat_col: int, sv: dict, base: int) -> List[Op]:
         """`base` = ops already in the backward plan (bucket-ready markers are absolute positions)."""
@@ -1006,15 +1241,18 @@ class TrainStep:
         gb = lambda name: st.grad_view(name) if st.trainable(name) else self._frozen_dw[Dm:2 * Dm]   # 2nd sink: LN dw + db
         lb = self._lin_bwd
         dx, dx2 = sv["dxa"], sv["dxb"]
-        plan: List[Op] = [T.fill_zero(self._wide.get(dx.data_ptr(), dx), run=False),
-                          T.map_rows(self.dfeats[:, feat_col:feat_col + Dm], dx, rows=B * 256, group=256, stride=Tk,
-                                     offset=t.n_prefix, scatter=True, run=False)]
+        seq, j0 = self._vseq_bwd, self._vseq_bwd.index(self._vkey(tw, t.n_run - 1))
+        whole: List[Op] = [T.fill_zero(self._wide.get(dx.data_ptr(), dx), run=False),
+                           T.map_rows(self.dfeats[:, feat_col:feat_col + Dm], dx, rows=B * 256, group=256, stride=Tk,
+                                      offset=t.n_prefix, scatter=True, run=False)]
         lq, lo = sv["qkv"][0].stride(0), sv["ao"][0].stride(0)
         assert sv["dqkv"].stride(0) == lq and sv["dao"].stride(0) == lo
         strides, so = (Tk * lq, hd, lq), (Tk * lo, hd, lo)
         for i in range(t.n_run - 1, -1, -1):
             b, bn = tw.blocks[i], f"{p}.blocks.{i}"
             dbr = dx
+            plan: List[Op] = []                    # this block's ops: one parameter-sharded unit
+            self._cur_unit = self._vkey(tw, i) if self._vkey(tw, i) in self._units else None
             if b.ls2 is not None:
                 plan.append(T.layerscale_backward(dx, sv["u2"][i], b.ls2, sv["du"], gv(f"{bn}.ls2.scale_factor"), self.col_ws, run=False))
                 dbr = sv["du"]
@@ -1037,10 +1275,14 @@ class TrainStep:
                                              o_strides=so, causal=False, run=False))
             plan += self._bias_grad(dq, f"{bn}.attn.qkv.bias")
             plan += lb(dq, sv["h1"][i], b.qkv_w, sv["dh"])
-            self._ready.append((base + len(plan), f"vision.{tower_key}.block{i:02d}"))
-            plan.append(T.layernorm_backward(sv["x"][i], b.norm1_w, sv["dh"], dx, gv(f"{bn}.norm1.weight"), gb(f"{bn}.norm1.bias"),
-                                             self.norm_ws, eps, dres=dx2, run=False))
+            self._cur_unit = None
+            whole += self._u_seq(seq, j0 + (t.n_run - 1 - i), True, plan)
+            self._ready.append((base + len(whole), f"vision.{tower_key}.block{i:02d}"))
+            whole.append(T.layernorm_backward(sv["x"][i], b.norm1_w, sv["dh"], dx, gv(f"{bn}.norm1.weight"), gb(f"{bn}.norm1.bias"),
+                                              self.norm_ws, eps, dres=dx2, run=False))
         # stem: dx = gradient of [prefix tokens | patch embeddings + pos]
+        plan = []
+        self._cur_unit = self._vkey(tw, -1) if self._vkey(tw, -1) in self._units else None
         if st.trainable(f"{p}.pos_embed"):
             dxv = dx.view(B, Tk * Dm)
             plan.append(T.colsum(dxv[:, t.n_prefix * Dm:], st.grad_view(f"{p}.pos_embed"), self.col_ws, run=False))
@@ -1051,8 +1293,10 @@ class TrainStep:
             plan.append(T.map_rows(dx, sv["dpe"], rows=B * 256, group=256, stride=Tk, offset=t.n_prefix, scatter=False, run=False))
             plan += self._bias_grad(sv["dpe"], f"{p}.patch_embed.proj.bias")
             plan += self._wgrad(sv["dpe"], self._vis.vbuf[1 if feat_col else 0]["col"], tw.patch_w)
-        self._ready.append((base + len(plan), f"vision.{tower_key}.stem"))
-        return plan
+        self._cur_unit = None
+        whole += self._u_seq(seq, j0 + t.n_run, True, plan)
+        self._ready.append((base + len(whole), f"vision.{tower_key}.stem"))
+        return whole
 
     def _lowest_needed_layer(self) -> int:
         """Backward stops above the lowest decoder layer that still has a trainable tensor below or inside it."""
@@ -1074,7 +1318,7 @@ class TrainStep:
         # plain tensors (norm scales, biases, embeddings, LoRA adapters): updated bf16 values → the live tensors, as prepared
         # byte copies inside the plan (hundreds of them under LoRA: replayed with the graph instead of launched one by one)
         for u in st.units:
-            if u.group is None:
+            if u.group is None and st.layout.buckets[u.bucket].key not in st.sharded_keys:
                 assert u.dst.is_contiguous()
                 plan.append(T.copy_f32(st.stage_view(u.offset, u.numel), u.dst, run=False))
         for u in st.units:
@@ -1121,7 +1365,7 @@ class TrainStep:
     def _replay(self, key: str, plan: List[Op], graph: bool) -> None:
         if self._materialized:
             raise RuntimeError("materialize_params() ended this step object's training (its plans address the gather slots)")
-        if not graph or (self.shard_params and key in ("fwd", "bwd")):      # per-layer collectives stay out of HIP graphs
+        if not graph or (self.shard_params and key in ("vfwd", "fwd", "bwd")):      # per-unit collectives stay out of HIP graphs
             ops.run_all(plan)
             return
         gr = self._graphs.get(key)

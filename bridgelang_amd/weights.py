@@ -393,6 +393,11 @@ class VLAWeights:
     layer_arena: Optional[Arena] = None      # the decoder layers' GEMM weights: a second allocation that parameter-sharded
                                              # training can give back (release_layer_weights)
     _layer_views: List[tuple] = field(default_factory=list)             # (layer index, field, group index, arena view index)
+    # the other FSDP units (prismatic.py:285-306: every ViT block, the projector; fsdp.py:160-168: the root's embeddings and
+    # lm_head) in two more releasable allocations: "vision" (patch embeddings + blocks of both towers) and "head"
+    # (projector, token embeddings, lm_head). Parameter-sharded training re-points their tensors at gather slots too.
+    unit_arenas: Dict[str, Arena] = field(default_factory=dict)
+    _unit_views: List[tuple] = field(default_factory=list)  # (pool, unit key, path to the attribute, group index | None, view index, HF name | None)
 
     # ---- parameter-sharded training (training/step.py, shard_params): decoder-layer GEMM weights leave the device -------
     @property
@@ -427,6 +432,50 @@ class VLAWeights:
             t = self.layer_arena.view(idx)
             setattr(self.layers[l], key, t)
             self.groups[gi].packed = t
+
+    # ---- the same for the vision / head units -----------------------------------------------------------------------------
+    def _attr_of(self, path: tuple):
+        obj = self
+        for q in path[:-1]:
+            obj = getattr(obj, q) if isinstance(q, str) else obj[q]
+        return obj, path[-1]
+
+    def pool_resident(self, pool: str) -> bool:
+        a = self.unit_arenas.get(pool)
+        return a is not None and a.buf is not None
+
+    def unit_fields(self, pool: str) -> List[tuple]:
+        """(unit key, attribute path, group index or None, HF name or None) of every tensor of the pool, allocation order."""
+        return [(key, path, gi, name) for pl, key, path, gi, _, name in self._unit_views if pl == pool]
+
+    def repoint_unit_weights(self, pool: str, views: Dict[tuple, torch.Tensor]) -> None:
+        """views[(unit key, attribute path)] = the tensor (a gather-slot view of the same shape) that replaces it."""
+        for pl, key, path, gi, _, name in self._unit_views:
+            if pl != pool or (key, path) not in views:
+                continue
+            t = views[(key, path)]
+            obj, attr = self._attr_of(path)
+            assert tuple(t.shape) == tuple(getattr(obj, attr).shape), (key, path)
+            setattr(obj, attr, t)
+            if gi is not None:
+                self.groups[gi].packed = t
+            if name is not None:
+                self.placements[name].dst = t
+
+    def release_unit_weights(self, pool: str, views: Dict[tuple, torch.Tensor]) -> int:
+        if not self.pool_resident(pool):
+            raise RuntimeError(f"the {pool} weights are not resident")
+        self.repoint_unit_weights(pool, views)
+        self.unit_arenas[pool].buf = None
+        return self.unit_arenas[pool].nbytes
+
+    def restore_unit_weights(self, pool: str) -> None:
+        """Re-allocate the pool (zero-filled; the caller gathers and packs)."""
+        if self.pool_resident(pool):
+            return
+        arena = self.unit_arenas[pool]
+        arena.commit()
+        self.repoint_unit_weights(pool, {(key, path): arena.view(idx) for pl, key, path, gi, idx, name in self._unit_views if pl == pool})
 
     def _specs(self, recipe: str = "init") -> Dict[str, TensorSpec]:
         return {s.name: s for s in tensor_specs(self.dims, recipe)}
@@ -514,6 +563,9 @@ def allocate(dims: VLADims, device: torch.device | str = "cuda") -> VLAWeights:
     device = torch.device(device)
     arena = Arena(device)
     layer_arena = Arena(device)                  # decoder-layer GEMM weights (see VLAWeights.release_layer_weights)
+    unit_arenas = {"vision": Arena(device), "head": Arena(device)}   # the other FSDP units (see VLAWeights.release_unit_weights)
+    unit_views: List[tuple] = []
+    pending_units: List[Tuple[str, int, Callable[[torch.Tensor], None]]] = []
     layer_views: List[tuple] = []
     pending: List[Tuple[int, Callable[[torch.Tensor], None]]] = []
     pending_layers: List[Tuple[int, Callable[[torch.Tensor], None]]] = []
@@ -524,10 +576,15 @@ def allocate(dims: VLADims, device: torch.device | str = "cuda") -> VLAWeights:
     def dense(holder, key, shape):
         pending.append((arena.reserve(tuple(shape)), lambda x, h=holder, k=key: h.__setitem__(k, x)))
 
-    def gemm_w(holder, key, n, k, layer: Optional[int] = None) -> int:
+    def gemm_w(holder, key, n, k, layer: Optional[int] = None, unit: Optional[tuple] = None) -> int:
+        """`unit` = (pool, bucket key, attribute path on the finished VLAWeights) for the vision / head units."""
         assert n % 16 == 0 and k % 64 == 0, (key, n, k)
         setter = lambda x, h=holder, kk=key: h.__setitem__(kk, x)
-        if layer is None:
+        if unit is not None:
+            idx = unit_arenas[unit[0]].reserve((n // 16, k // 32, 64, 8))
+            pending_units.append((unit[0], idx, setter))
+            unit_views.append((unit[0], unit[1], unit[2], len(group_defs), idx, None))
+        elif layer is None:
             pending.append((arena.reserve((n // 16, k // 32, 64, 8)), setter))
         else:
             idx = layer_arena.reserve((n // 16, k // 32, 64, 8))
@@ -536,10 +593,12 @@ def allocate(dims: VLADims, device: torch.device | str = "cuda") -> VLAWeights:
         group_defs.append((holder, key, n, k))
         return len(group_defs) - 1
 
-    def tower(t: TowerDims) -> dict:
+    def tower(t: TowerDims, attr: str) -> dict:
         h = {"blocks": [dict() for _ in range(t.n_run)]}
         p, D, Hp, kp = t.prefix, t.dim, t.mlp_pad, _pad64(dims.patch_k)
-        g = gemm_w(h, "patch_w", D, kp); grouped[f"{p}.patch_embed.proj.weight"] = (g, 0, D, dims.patch_k, kp)
+        tk = p.split(".")[1]                       # bucket keys as training/sharding.py::bucket_key names them
+        g = gemm_w(h, "patch_w", D, kp, unit=("vision", f"vision.{tk}.stem", (attr, "patch_w")))
+        grouped[f"{p}.patch_embed.proj.weight"] = (g, 0, D, dims.patch_k, kp)
         dense(h, "patch_b", (D,)); plain[f"{p}.patch_embed.proj.bias"] = (h, "patch_b", 0, 1, D, D)
         dense(h, "pos", (256, D)); plain[f"{p}.pos_embed"] = (h, "pos", 0, 256, D, D)
         if t.n_prefix:
@@ -555,10 +614,11 @@ def allocate(dims: VLADims, device: torch.device | str = "cuda") -> VLAWeights:
                 dense(b, key, (D,)); plain[f"{bn}.{hf}"] = (b, key, 0, 1, D, D)
             dense(b, "qkv_b", (3 * D,)); plain[f"{bn}.attn.qkv.bias"] = (b, "qkv_b", 0, 1, 3 * D, 3 * D)
             dense(b, "fc1_b", (Hp,)); plain[f"{bn}.mlp.fc1.bias"] = (b, "fc1_b", 0, 1, t.mlp, t.mlp)
-            g = gemm_w(b, "qkv_w", 3 * D, D); grouped[f"{bn}.attn.qkv.weight"] = (g, 0, 3 * D, D, D)
-            g = gemm_w(b, "proj_w", D, D); grouped[f"{bn}.attn.proj.weight"] = (g, 0, D, D, D)
-            g = gemm_w(b, "fc1_w", Hp, D); grouped[f"{bn}.mlp.fc1.weight"] = (g, 0, t.mlp, D, D)
-            g = gemm_w(b, "fc2_w", D, Hp); grouped[f"{bn}.mlp.fc2.weight"] = (g, 0, D, t.mlp, Hp)
+            un = lambda f: ("vision", f"vision.{tk}.block{i:02d}", (attr, "blocks", i, f))
+            g = gemm_w(b, "qkv_w", 3 * D, D, unit=un("qkv_w")); grouped[f"{bn}.attn.qkv.weight"] = (g, 0, 3 * D, D, D)
+            g = gemm_w(b, "proj_w", D, D, unit=un("proj_w")); grouped[f"{bn}.attn.proj.weight"] = (g, 0, D, D, D)
+            g = gemm_w(b, "fc1_w", Hp, D, unit=un("fc1_w")); grouped[f"{bn}.mlp.fc1.weight"] = (g, 0, t.mlp, D, D)
+            g = gemm_w(b, "fc2_w", D, Hp, unit=un("fc2_w")); grouped[f"{bn}.mlp.fc2.weight"] = (g, 0, D, t.mlp, Hp)
             if t.layerscale:
                 dense(b, "ls1", (D,)); plain[f"{bn}.ls1.scale_factor"] = (b, "ls1", 0, 1, D, D)
                 dense(b, "ls2", (D,)); plain[f"{bn}.ls2.scale_factor"] = (b, "ls2", 0, 1, D, D)
@@ -566,17 +626,21 @@ def allocate(dims: VLADims, device: torch.device | str = "cuda") -> VLAWeights:
                 b["ls1"] = b["ls2"] = None
         return h
 
-    hd, hs = tower(dims.dino), tower(dims.siglip)
+    hd, hs = tower(dims.dino, "dino"), tower(dims.siglip, "siglip")
     top: dict = {}
     V, P, L, I = dims.vision_dim, 4 * dims.vision_dim, dims.llm_dim, dims.llm_inter
     for key, hf, n, k in (("fc1_w", "projector.fc1.weight", P, V), ("fc2_w", "projector.fc2.weight", L, P),
                           ("fc3_w", "projector.fc3.weight", L, L)):
-        g = gemm_w(top, key, n, k); grouped[hf] = (g, 0, n, k, k)
+        g = gemm_w(top, key, n, k, unit=("head", "projector", (key,))); grouped[hf] = (g, 0, n, k, k)
     for key, hf, n in (("fc1_b", "projector.fc1.bias", P), ("fc2_b", "projector.fc2.bias", L),
                        ("fc3_b", "projector.fc3.bias", L)):
         dense(top, key, (n,)); plain[hf] = (top, key, 0, 1, n, n)
     lm = "language_model.model"
-    dense(top, "embed", (dims.vocab, L)); plain[f"{lm}.embed_tokens.weight"] = (top, "embed", 0, dims.vocab, L, L)
+    # token embeddings: a plain [vocab, L] tensor (gathered by row), but one of the root FSDP unit's two big parameters
+    idx = unit_arenas["head"].reserve((dims.vocab, L))
+    pending_units.append(("head", idx, lambda x: top.__setitem__("embed", x)))
+    unit_views.append(("head", "llm.embed", ("embed",), None, idx, f"{lm}.embed_tokens.weight"))
+    plain[f"{lm}.embed_tokens.weight"] = (top, "embed", 0, dims.vocab, L, L)
     layer_h = [dict() for _ in range(dims.llm_layers)]
     for i, lh in enumerate(layer_h):
         bn = f"{lm}.layers.{i}"
@@ -591,10 +655,15 @@ def allocate(dims: VLADims, device: torch.device | str = "cuda") -> VLAWeights:
         grouped[f"{bn}.mlp.up_proj.weight"] = (g, L, I, L, 2 * L)        # row 2j+1 = up_j
         g = gemm_w(lh, "down_w", L, I, layer=i); grouped[f"{bn}.mlp.down_proj.weight"] = (g, 0, L, I, I)
     dense(top, "norm", (L,)); plain[f"{lm}.norm.weight"] = (top, "norm", 0, 1, L, L)
-    g = gemm_w(top, "lm_head", dims.vocab, L); grouped["language_model.lm_head.weight"] = (g, 0, dims.vocab, L, L)
+    g = gemm_w(top, "lm_head", dims.vocab, L, unit=("head", "llm.lm_head", ("lm_head",)))
+    grouped["language_model.lm_head.weight"] = (g, 0, dims.vocab, L, L)
 
     arena.commit()
     layer_arena.commit()
+    for a in unit_arenas.values():
+        a.commit()
+    for pool, idx, setter in pending_units:
+        setter(unit_arenas[pool].view(idx))
     for idx, setter in pending:
         setter(arena.view(idx))
     for idx, setter in pending_layers:
@@ -607,6 +676,7 @@ def allocate(dims: VLADims, device: torch.device | str = "cuda") -> VLAWeights:
                    top["fc1_w"], top["fc1_b"], top["fc2_w"], top["fc2_b"], top["fc3_w"], top["fc3_b"], top["embed"],
                    [LayerW(**lh) for lh in layer_h], top["norm"], top["lm_head"])
     w.layer_arena, w._layer_views = layer_arena, layer_views
+    w.unit_arenas, w._unit_views = unit_arenas, unit_views
     w.groups = [PackedGroup(holder[key], n, k) for holder, key, n, k in group_defs]
     for name, (holder, key, off, rows, cols, ld) in plain.items():
         w.placements[name] = Placement(holder[key], off, rows, cols, ld)

@@ -29,8 +29,9 @@ dims = tiny_dims()
 w = allocate(dims, dev).fill_synthetic(seed=3)
 B, L = 4, 20
 rd = torch.bfloat16 if os.environ.get("BL_REDUCE") == "bf16" else torch.float32
+STAGE = os.environ.get("BL_STAGE", "vla-train")
 def run(w, shard_params):
-    ts = TrainStep(w, "vla-train", B // world, L, max_grad_norm=1.0, weight_decay=0.1, world=world, rank=rank, reduce_dtype=rd,
+    ts = TrainStep(w, STAGE, B // world, L, max_grad_norm=1.0, weight_decay=0.1, world=world, rank=rank, reduce_dtype=rd,
                    shard_params=shard_params)
     out = []
     for step in range(2):
@@ -46,16 +47,24 @@ live = {k: v.cpu() for k, v in w.state_dict().items()}
 # FULL_SHARD over two ranks: each rank keeps half of every decoder layer; results equal the replicated-weight run exactly
 w2 = allocate(dims, dev).fill_synthetic(seed=3)
 ts2, out2 = run(w2, True)
-assert not w2.layers_resident and ts2.store.own.numel() * world <= sum(b.numel for b in ts2.store.layout.buckets if b.key.startswith("llm.layer")) + 8
+sharded_total = sum(b.numel for b in ts2.store.layout.buckets if b.key in ts2.store.sharded_keys)
+assert not w2.layers_resident and ts2.store.own.numel() * world <= sharded_total + 8
+# every FSDP unit of the reference is parameter-sharded (prismatic.py:285-306, fsdp.py:160-168): decoder layers, projector, token
+# embeddings, lm_head, and — when the stage trains them — every ViT block and patch embedding; only the small plain tensors
+# (norm scales, biases, LayerScale, position / class tokens) stay replicated
+assert {"projector", "llm.lm_head", "llm.embed"} <= ts2.store.sharded_keys and not w2.pool_resident("head")
+assert (STAGE != "vla-full-train") or (any(k.startswith("vision.") for k in ts2.store.sharded_keys) and not w2.pool_resident("vision"))
+replicated = sum(b.numel for b in ts2.store.layout.buckets if b.key not in ts2.store.sharded_keys)
+assert replicated <= 0.02 * ts2.store.layout.total, "all but the norm scales / biases must be sharded"
 assert out2 == out, (out, out2)
 sd2 = ts2.store.master_state_dict(ts2.comm)
 assert all(torch.equal(sd[k], sd2[k]) for k in sd)
 # ... and so is the GRADIENT of every decoder layer: the flat fp32 gradient no longer covers the layer buckets, each rank
 # keeps 1/world of their reduced gradient, the full gradient of a layer lives in one of two transient slots
-layer_total = sum(b.numel for b in ts2.store.layout.buckets if b.key.startswith("llm.layer"))
+layer_total = sharded_total
 assert ts2.store.grad.numel() <= ts.store.grad.numel() - layer_total + 8
-assert ts2.store.gshard.numel() * world <= layer_total + 8 and len(ts2.store.gslots) == 2
-per_rank = lambda t: (t.store.grad.numel() + (t.store.gshard.numel() + sum(g.numel() for g in t.store.gslots) if t.store.gshard is not None else 0)) * 4
+assert ts2.store.gshard.numel() * world <= layer_total + 8 and all(len(g) == 2 for g in ts2.store.gslots.values())
+per_rank = lambda t: (t.store.grad.numel() + (t.store.gshard.numel() + sum(g.numel() for gs in t.store.gslots.values() for g in gs) if t.store.gshard is not None else 0)) * 4
 print(f"rank {rank}: fp32 gradient bytes per rank: shard-grad-op {per_rank(ts)}, full-shard {per_rank(ts2)} "
       f"(persistent {(ts2.store.grad.numel() + ts2.store.gshard.numel()) * 4} + 2 slots)", flush=True)
 ts2.materialize_params()
@@ -64,7 +73,7 @@ assert all(torch.equal(live[k], live2[k].cpu()) for k in live)
 # gradient accumulation under the sharded optimizer (vla-scripts/finetune.py:264,315 grad_accumulation_steps): two
 # micro-batches per optimizer step, each reduced over the ranks, accumulated as this rank's slices
 def run_accum(w, shard_params):
-    ts = TrainStep(w, "vla-train", B // world, L, max_grad_norm=1.0, weight_decay=0.1, world=world, rank=rank, reduce_dtype=rd,
+    ts = TrainStep(w, STAGE, B // world, L, max_grad_norm=1.0, weight_decay=0.1, world=world, rank=rank, reduce_dtype=rd,
                    shard_params=shard_params)
     out = []
     for step in range(2):
@@ -90,14 +99,26 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("reduce", ["fp32", "bf16"])
-def test_two_rank_sharded_step_matches_single_process(dev, tmp_path, reduce):
+def _free_port() -> str:
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return str(so.getsockname()[1])
+
+
+@pytest.mark.parametrize("reduce,stage", [("fp32", "vla-train"), ("bf16", "vla-train"), ("fp32", "vla-full-train")])
+def test_two_rank_sharded_step_matches_single_process(dev, tmp_path, reduce, stage):
+    """Two ranks (shard-grad-op AND full-shard, which must agree bit for bit inside the worker) against ONE process stepping
+    on the whole batch. The comparison with the un-sharded run is loose by construction — each rank sees half of the batch,
+    so every bf16 rounding of its activations / output gradients differs from the whole-batch run's (and the fp32 sums are
+    split differently): the global gradient norm agrees to 5e-3 (fp32 wire) / 3e-2 (bf16 wire), updates to cosine 0.98 / 0.90.
+    The strong assertions are the bit-identities between the two sharding modes in the worker."""
     from bridgelang_amd.training.step import TrainStep
     from bridgelang_amd.weights import allocate, tiny_dims
     dims = tiny_dims()
     w = allocate(dims, dev).fill_synthetic(seed=3)
     B, L = 4, 20
-    ts = TrainStep(w, "vla-train", B, L, max_grad_norm=1.0, weight_decay=0.1)
+    ts = TrainStep(w, stage, B, L, max_grad_norm=1.0, weight_decay=0.1)
     log = []
     for step in range(2):
         ids, mask, labels, pv = make_batch(dims, B, L, seed=20 + step, ragged=False)
@@ -108,8 +129,8 @@ def test_two_rank_sharded_step_matches_single_process(dev, tmp_path, reduce):
     torch.cuda.synchronize()
     script, out = tmp_path / "worker.py", tmp_path / "out.pt"
     script.write_text(_WORKER)
-    env = dict(os.environ, BL_ROOT=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT="29551", WORLD_SIZE="2", BL_OUT=str(out),
-               BL_REDUCE=reduce)
+    env = dict(os.environ, BL_ROOT=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="2", BL_OUT=str(out),
+               BL_REDUCE=reduce, BL_STAGE=stage)
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
@@ -129,7 +150,7 @@ def test_two_rank_sharded_step_matches_single_process(dev, tmp_path, reduce):
     print("worst update cosine", worst)
     # gradient accumulation: two micro-batches per step, single process on the whole micro-batches vs the two sharded ranks
     w3 = allocate(dims, dev).fill_synthetic(seed=3)
-    ts3 = TrainStep(w3, "vla-train", B, L, max_grad_norm=1.0, weight_decay=0.1)
+    ts3 = TrainStep(w3, stage, B, L, max_grad_norm=1.0, weight_decay=0.1)
     norms = []
     for step in range(2):
         for micro in range(2):
@@ -197,6 +218,6 @@ def test_sharded_step_over_rccl_single_rank(dev, tmp_path):
     must reproduce the collective-free step bit for bit; bf16 reduction within its rounding."""
     script = tmp_path / "worker.py"
     script.write_text(_RCCL_WORKER)
-    env = dict(os.environ, BL_ROOT=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    env = dict(os.environ, BL_ROOT=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout[-3000:]
