@@ -369,10 +369,11 @@ def train_line(args, rank: int, world: int, dev) -> dict:
                                     + (f"; optimizer state sharded over {world} ranks, {args.reduce} gradient reduce-scatter "
                                        f"per bucket overlapped with backward, bf16 weight all-gather" if world > 1 else "")),
                        "batch_per_gpu": B, "global_batch": B * world, "seq_len": ts.S, "stage": args.stage,
-                       "parallelism": (f"dp{world} sharded-optimizer ({'full-shard: decoder-layer parameters sharded' if args.shard_params else 'shard-grad-op'})"
+                       "parallelism": (f"dp{world} sharded-optimizer ({'full-shard: every FSDP unit's parameters and gradients sharded' if args.shard_params else 'shard-grad-op'})"
                                        if world > 1 else "single GPU"),
                        "hip_graph": graph, "recompute_activations": bool(args.recompute), "shard_params": bool(args.shard_params), "fp8_fwd_dgrad": bool(args.fp8),
-                       "fp8_wgrad": bool(getattr(args, "fp8_wgrad", False))},
+                       "fp8_wgrad": bool(getattr(args, "fp8_wgrad", False)),
+                       "fp8_wgrad_gemms": {"e4m3": ts.fp8_wgrad_gemms[0], "bf16_fallback": ts.fp8_wgrad_gemms[1]}},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": train_traffic,
                          "traffic_note": "avg HBM+Infinity-Cache bytes per forward bl_gemm_bf16 call over the 4 decoder-layer GEMM shapes at "

@@ -68,6 +68,8 @@ SIGNATURES = {
     "bl_pack_weight_bf16": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "bl_gemm_fp8": (C.c_int, [C.POINTER(GemmDesc), _vp, _vp, _vp]),
     "bl_quantize_rows_fp8": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "bl_colamax_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "bl_transpose_quantize_fp8": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
     "bl_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "bl_gemm_skinny_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "bl_gemm_skinny_rows_bf16": (C.c_int, [C.POINTER(GemmDesc), _vp]),

@@ -89,6 +89,26 @@ def transpose_pad(a, out, rows_pad: int, run: bool = True) -> Op:
                                          _rows(out, "out"), rows_pad), (a, out), run, nbytes=2.0 * cols * (rows + rows_pad))
 
 
+def colamax(x: torch.Tensor, amax: torch.Tensor, run: bool = True) -> Op:
+    """amax[c] = max(amax[c], max_t |x[t, c]|) (fp32; zero it first): per-channel scales of the e4m3 weight-gradient operands."""
+    rows, cols = x.shape
+    assert amax.dtype == torch.float32 and amax.numel() >= cols
+    return _op("bl_colamax_bf16", (_bf16(x, "x").data_ptr(), _rows(x, "x"), rows, cols, amax.data_ptr()), (x, amax), run,
+               nbytes=2.0 * rows * cols)
+
+
+def transpose_quantize_fp8(x: torch.Tensor, amax: torch.Tensor, q: torch.Tensor, scales: torch.Tensor, tokens_pad: int, packed: bool,
+                           run: bool = True) -> Op:
+    """x bf16 [tokens, channels] → e4m3 codes, token-contiguous per channel (tokens zero-padded to tokens_pad) + scales[c] =
+    amax[c] / 448: q uint8 [channels, tokens_pad] row-major, or (packed) in bl_gemm_fp8's weight-operand packing
+    [channels / 16, tokens_pad / 64, 64, 16]. One pass: 2 B read + 1 B written per element."""
+    rows, cols = x.shape
+    assert q.dtype == torch.uint8 and q.is_contiguous() and q.numel() == cols * tokens_pad and scales.numel() >= cols
+    return _op("bl_transpose_quantize_fp8", (_bf16(x, "x").data_ptr(), _rows(x, "x"), rows, cols, amax.data_ptr(), q.data_ptr(),
+                                             tokens_pad, int(packed), scales.data_ptr()), (x, amax, q, scales), run,
+               nbytes=3.0 * rows * cols)
+
+
 def map_rows(src, dst, *, rows: int, group: int, stride: int, offset: int, scatter: bool, run: bool = True) -> Op:
     cols = src.shape[1]
     return _op("bl_map_rows_bf16", (_bf16(src, "src").data_ptr(), _rows(src, "src"), _bf16(dst, "dst").data_ptr(), _rows(dst, "dst"),

@@ -33,6 +33,7 @@ from .sharding import ShardComm, ShardLayout, bucket_key, comm_order
 
 IGNORE_INDEX = -100
 WGRAD_NT = os.environ.get("BL_WGRAD_NT", "") not in ("", "0")     # A/B aid: weight gradients through transposed copies
+WGRAD_FP8_5PASS = os.environ.get("BL_WGRAD_FP8_5PASS", "") not in ("", "0")   # A/B aid: round 3's five passes per e4m3 wgrad operand pair
 # SwiGLU / GELU forward ("f") and backward ("b") as GEMM epilogues (BL_EPI_*_KEEP / BL_EPI_*_BWD) instead of separate
 # elementwise passes. OFF by default — measured on one MI355X at 7B, B = 32 (round 4, same box, alternating runs): separate
 # passes 442.2 ms / step, backward fused 442.7, forward fused 446.2, both 444.5. The tile GEMM holds one workgroup per CU, so
@@ -384,6 +385,7 @@ class TrainStep:
         if fp8_wgrad and not fp8:
             raise ValueError("fp8_wgrad extends fp8=True (e4m3 forward / dgrad) to the weight-gradient GEMMs")
         self.fp8, self.fp8_wgrad = fp8, fp8_wgrad
+        self.fp8_wgrad_gemms = [0, 0]          # planned weight-gradient GEMMs [on the e4m3 path, fallen back to bf16]
         self.recompute, self.shard_params = recompute, shard_params
         self.lora = lora
         self.train_vision = STAGES[stage][0] or lora is not None      # towers need their training-form forward
@@ -532,12 +534,15 @@ class TrainStep:
             Tq = (Tn + 127) // 128 * 128       # its contraction length: tokens, padded with zero columns to the MFMA's K = 128
             nmx = max(3 * D, 2 * I)
             self._Tq = Tq
-            self._wg_tA = torch.zeros(nmx * Tq, dtype=torch.bfloat16, device=dev)      # dyᵀ [N, Tq] bf16
-            self._wg_tB = torch.zeros(I * Tq, dtype=torch.bfloat16, device=dev)        # xᵀ  [K, Tq] bf16
-            self._wg_qA, self._wg_qB = u8(nmx * Tq), u8(I * Tq)                        # their e4m3 codes
-            self._wg_pB = torch.zeros(I * Tq // 2, dtype=torch.bfloat16, device=dev)   # xᵀ codes in the fragment-major packing
+            self._wg_qA = u8(nmx * Tq)                                                 # dyᵀ codes [N, Tq] row-major
+            self._wg_pB = u8(I * Tq)                                                   # xᵀ codes [K, Tq] in the fragment-major packing
             self._wg_sA = torch.zeros(nmx, dtype=torch.float32, device=dev)
             self._wg_sB = torch.zeros(I, dtype=torch.float32, device=dev)
+            self._wg_amax = torch.zeros(nmx + I, dtype=torch.float32, device=dev)      # column |max| of dy (first N) and x (next K)
+            if WGRAD_FP8_5PASS:                # A/B aid: the round-3 form through separate transpose / quantise / pack passes
+                self._wg_tA = torch.zeros(nmx * Tq, dtype=torch.bfloat16, device=dev)
+                self._wg_tB = torch.zeros(I * Tq, dtype=torch.bfloat16, device=dev)
+                self._wg_qB = u8(I * Tq)
         self._fp8_scratch()
         if self.shard_params:                  # sharded layers are quantised in their gather (slots carry the e4m3 copies)
             return
@@ -890,13 +895,21 @@ class TrainStep:
         assert tuple(gview.shape) == (N, K), (dy.shape, x.shape, gview.shape)
         if fp8:
             Tq = self._Tq
-            tA, tB = self._wg_tA[:N * Tq].view(N, Tq), self._wg_tB[:K * Tq].view(K, Tq)
-            qA, qB = self._wg_qA[:N * Tq].view(N, Tq), self._wg_qB[:K * Tq].view(K, Tq)
-            pB = self._wg_pB[:K * Tq // 2].view(K // 16, Tq // 64, 64, 8)
+            qA = self._wg_qA[:N * Tq].view(N, Tq)
+            pB = self._wg_pB[:K * Tq].view(torch.bfloat16).view(K // 16, Tq // 64, 64, 8)
             sA, sB = self._wg_sA[:N], self._wg_sB[:K]
-            return [T.transpose_pad(dy, tA, Tq, run=False), ops.quantize_rows_fp8(tA, qA, sA, run=False)[2],
-                    T.transpose_pad(x, tB, Tq, run=False), ops.quantize_rows_fp8(tB, qB, sB, run=False)[2],
-                    T.pack(qB.view(torch.bfloat16), pB, run=False), ops.gemm_fp8(qA, sA, pB, sB, gview, EPI_F32, run=False)]
+            if WGRAD_FP8_5PASS:
+                tA, tB = self._wg_tA[:N * Tq].view(N, Tq), self._wg_tB[:K * Tq].view(K, Tq)
+                qB = self._wg_qB[:K * Tq].view(K, Tq)
+                return [T.transpose_pad(dy, tA, Tq, run=False), ops.quantize_rows_fp8(tA, qA, sA, run=False)[2],
+                        T.transpose_pad(x, tB, Tq, run=False), ops.quantize_rows_fp8(tB, qB, sB, run=False)[2],
+                        T.pack(qB.view(torch.bfloat16), pB, run=False), ops.gemm_fp8(qA, sA, pB, sB, gview, EPI_F32, run=False)]
+            # two passes per operand: column |max| (2 B read), then one transposing quantise(-and-pack) (2 B read, 1 B written)
+            am = self._wg_amax[:N + K]
+            return [T.fill_zero(am, run=False), T.colamax(dy, am[:N], run=False), T.colamax(x, am[N:], run=False),
+                    T.transpose_quantize_fp8(dy, am[:N], self._wg_qA[:N * Tq], sA, Tq, False, run=False),
+                    T.transpose_quantize_fp8(x, am[N:], self._wg_pB[:K * Tq], sB, Tq, True, run=False),
+                    ops.gemm_fp8(qA, sA, pB, sB, gview, EPI_F32, run=False)]
         if not WGRAD_NT and N % 8 == 0 and K % 8 == 0:
             return [T.gemm_tn(dy, x, gview, workspace=self.ws, run=False)]
         Tp = (Tn + 63) // 64 * 64
@@ -915,7 +928,14 @@ class TrainStep:
         u = self._unit_of(packed)
         if u is None:
             return []
-        fp8 = self.fp8_wgrad and packed.data_ptr() in self._w8 and dy.shape[1] % 16 == 0 and x.shape[1] % 16 == 0
+        want = self.fp8_wgrad and packed.data_ptr() in self._w8
+        fp8 = want and dy.shape[1] % 16 == 0 and x.shape[1] % 16 == 0
+        if want:                               # how many weight-gradient GEMMs really run on the e4m3 path (bench.py reports it)
+            self.fp8_wgrad_gemms[0 if fp8 else 1] += 1
+            if not fp8 and self.fp8_wgrad_gemms[1] == 1:
+                import warnings
+                warnings.warn(f"fp8_wgrad: a weight gradient of shape [{dy.shape[1]}, {x.shape[1]}] is not a multiple of 16 in both "
+                              "dimensions and stays on the bf16 TN GEMM")
         return self._wgrad_into(dy, x, self.store.grad_view(u), fp8=fp8)
 
     def _build_extended_weights(self) -> None:

@@ -146,6 +146,15 @@ int bl_gemm_fp8(const bl_gemm_desc* d, const float* scale_a, const float* scale_
  * q = RNE_e4m3(x * (448 / amax)). */
 int bl_quantize_rows_fp8(const bl_bf16* x, int64_t ldx, int32_t rows, int32_t cols, uint8_t* q, int64_t ldq, float* scales,
                          void* stream);
+/* Weight-gradient operands of the e4m3 path (dW = dyT . x contracts over tokens: one scale per CHANNEL, token-contiguous
+ * codes). bl_colamax_bf16: amax[c] = max_t |x[t, c]| into a PRE-ZEROED fp32 vector (atomic max; several calls may
+ * accumulate into one vector). bl_transpose_quantize_fp8: x bf16 [rows = tokens, cols = channels] -> e4m3 codes
+ * q[c][t] = rne(x[t, c] * 448 / amax[c]), tokens zero-padded to ldq (a multiple of 64), scales[c] = amax[c] / 448 (1 for an
+ * all-zero channel); packed = 0: q row-major [cols, ldq] (bl_gemm_fp8's activation operand), packed = 1: q in the
+ * fragment-major packing of its weight operand, [cols/16][ldq/64][64][16 B]. No reference counterpart. */
+int bl_colamax_bf16(const bl_bf16* x, int64_t ldx, int32_t rows, int32_t cols, float* amax, void* stream);
+int bl_transpose_quantize_fp8(const bl_bf16* x, int64_t ldx, int32_t rows, int32_t cols, const float* amax, uint8_t* q,
+                              int64_t ldq, int32_t packed, float* scales, void* stream);
 
 /* ---- normalisation ------------------------------------------------------------------------------------------ */
 /* timm Block.norm1/norm2: LayerNorm(eps, affine), fp32 statistics, bf16 out. y may alias x. */

@@ -123,3 +123,36 @@ def test_engine_fp8_prefill_close_to_bf16(dev):
     rel = ((la - lb).abs().amax() / la.abs().amax()).item()
     print(f"\nfp8 prefill vs bf16: max |dlogit| / scale = {rel:.4f}; first tokens equal: {(a[:, 0] == b[:, 0]).float().mean().item():.2f}")
     assert 0 < rel <= 0.08
+
+
+@pytest.mark.parametrize("T_,C_", [(592, 256), (9472 // 4, 1024), (130, 64), (257, 208)])
+def test_transposing_quantise_equals_the_five_pass_form(dev, T_, C_):
+    """The weight-gradient operands of the e4m3 path: bl_colamax_bf16 + bl_transpose_quantize_fp8 (read the bf16 [tokens,
+    channels] matrix once, write token-contiguous e4m3 codes — row-major for the GEMM's activation side, fragment-major
+    packed for its weight side) must reproduce round 3's transpose → quantise-rows → pack chain bit for bit: same
+    per-channel scales (amax / 448), same RNE codes, zero padding of the token tail."""
+    from bridgelang_amd import ops, train_ops as T
+    from conftest import rand_bf16
+    x = (rand_bf16((T_, C_), 3, 1.0) * torch.linspace(0.01, 30.0, C_)).to(torch.bfloat16).float()
+    x[:, 5] = 0.0                                                  # an all-zero channel: scale 1, codes 0
+    X = x.to(torch.bfloat16).to(dev)
+    Tq = (T_ + 127) // 128 * 128
+    # reference chain
+    tX = torch.zeros(C_, Tq, dtype=torch.bfloat16, device=dev)
+    T.transpose_pad(X, tX, Tq)
+    q_ref, s_ref, _ = ops.quantize_rows_fp8(tX)
+    # fused
+    amax = torch.zeros(C_, dtype=torch.float32, device=dev)
+    T.colamax(X, amax)
+    assert torch.equal(amax.cpu(), x.abs().amax(0))
+    q = torch.full((C_ * Tq,), 0x55, dtype=torch.uint8, device=dev)
+    s = torch.zeros(C_, dtype=torch.float32, device=dev)
+    T.transpose_quantize_fp8(X, amax, q, s, Tq, False)
+    assert torch.equal(s, s_ref) and s[5].item() == 1.0
+    assert torch.equal(q.view(C_, Tq), q_ref), f"{(q.view(C_, Tq) != q_ref).sum().item()} codes differ"
+    if C_ % 16 == 0:
+        p_ref = torch.zeros(C_ // 16, Tq // 64, 64, 8, dtype=torch.bfloat16, device=dev)
+        T.pack(q_ref.view(torch.bfloat16), p_ref)
+        qp = torch.full((C_ * Tq,), 0x55, dtype=torch.uint8, device=dev)
+        T.transpose_quantize_fp8(X, amax, qp, s, Tq, True)
+        assert torch.equal(qp.view(torch.bfloat16).view(p_ref.shape).view(torch.int16), p_ref.view(torch.int16))

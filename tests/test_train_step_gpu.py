@@ -286,7 +286,9 @@ def test_fp8_wgrad_close_to_bf16_wgrad(dev):
             N, K, Tq = 3 * dims.llm_dim, dims.llm_dim, ts._Tq
             ts.forward(); ts.backward()                           # scratch + gradient of the same (post-update) step
             qa = ts._wg_qA[:N * Tq].view(N, Tq).view(torch.float8_e4m3fn).double().cpu()
-            qb = ts._wg_qB[:K * Tq].view(K, Tq).view(torch.float8_e4m3fn).double().cpu()
+            from bridgelang_amd import ops
+            pb = ts._wg_pB[:K * Tq].view(torch.bfloat16).view(K // 16, Tq // 64, 64, 8)        # fragment-major packed codes of xᵀ
+            qb = ops.unpack_weight(pb).contiguous().view(torch.uint8).view(K, Tq).view(torch.float8_e4m3fn).double().cpu()
             want = (ts._wg_sA[:N].double().cpu()[:, None] * ts._wg_sB[:K].double().cpu()[None, :]) * (qa @ qb.t())
             u = ts._unit_of(w.layers[0].qkv_w)
             got = ts.store.grad_view(u).double().cpu()
