@@ -369,7 +369,7 @@ def train_line(args, rank: int, world: int, dev) -> dict:
                                     + (f"; optimizer state sharded over {world} ranks, {args.reduce} gradient reduce-scatter "
                                        f"per bucket overlapped with backward, bf16 weight all-gather" if world > 1 else "")),
                        "batch_per_gpu": B, "global_batch": B * world, "seq_len": ts.S, "stage": args.stage,
-                       "parallelism": (f"dp{world} sharded-optimizer ({'full-shard: every FSDP unit's parameters and gradients sharded' if args.shard_params else 'shard-grad-op'})"
+                       "parallelism": (f"dp{world} sharded-optimizer ({'full-shard: parameters and gradients of all FSDP units sharded' if args.shard_params else 'shard-grad-op'})"
                                        if world > 1 else "single GPU"),
                        "hip_graph": graph, "recompute_activations": bool(args.recompute), "shard_params": bool(args.shard_params), "fp8_fwd_dgrad": bool(args.fp8),
                        "fp8_wgrad": bool(getattr(args, "fp8_wgrad", False)),
