@@ -290,7 +290,8 @@ __global__ void resample_pass_kernel(const uint8_t* src, uint8_t* dst, int B, in
 // experiments/robot/openvla_utils.py:81-155: convert_image_dtype(uint8 → float32) → crop_and_resize(bilinear, one centred
 // box) → clip [0, 1] → convert_image_dtype(float32 → uint8, saturate) ), one thread per output pixel (3 channels):
 //   ys = y_base + i · y_step, xs likewise (fp32, the two constants come from the host so both sides use the same bits);
-//   0 outside [0, H-1] × [0, W-1]; else v = (1-wy)·((1-wx)·p00 + wx·p01) + wy·((1-wx)·p10 + wx·p11) on p = u8 · (1/255)
+//   0 outside [0, H-1] × [0, W-1]; else, on p = u8 · (1/255), TF's own form (crop_and_resize_op.cc): top = tl + (tr − tl)·x_lerp,
+//   bottom = bl + (br − bl)·x_lerp, v = top + (bottom − top)·y_lerp with lerp = in − floor(in), neighbours floor / ceil
 //   out = (uint8) clamp(clamp(v, 0, 1) · 255.5, 0, 255)       (TF scales by 255.5 and truncates when it saturates).
 // Every fp32 operation is a separate, individually rounded instruction (no FMA contraction), in the order of the host
 // restatement vla/eval_preprocess.py::crop_and_resize_bilinear — results are bit-identical to it.
@@ -309,10 +310,9 @@ __global__ void crop_resize_bilinear_kernel(const uint8_t* src, uint8_t* dst, in
     uint8_t* q = dst + t * 3;
     if (!(ys >= 0.0f && ys <= (float)(H - 1) && xs >= 0.0f && xs <= (float)(W - 1))) { q[0] = q[1] = q[2] = 0; continue; }
     const float fy = floorf(ys), fx = floorf(xs);
-    const float wy = ys - fy, wx = xs - fx;
-    const float wy1 = 1.0f - wy, wx1 = 1.0f - wx;
-    const int y0 = min(max((int)fy, 0), H - 1), y1 = min(max((int)fy + 1, 0), H - 1);
-    const int x0 = min(max((int)fx, 0), W - 1), x1 = min(max((int)fx + 1, 0), W - 1);
+    const float wy = ys - fy, wx = xs - fx;                        // TF: y_lerp = in_y - top_y_index
+    const int y0 = min(max((int)fy, 0), H - 1), y1 = min(max((int)ceilf(ys), 0), H - 1);
+    const int x0 = min(max((int)fx, 0), W - 1), x1 = min(max((int)ceilf(xs), 0), W - 1);
     const uint8_t* r0 = src + (b * H + y0) * (long)W * 3;
     const uint8_t* r1 = src + (b * H + y1) * (long)W * 3;
     const float k = 1.0f / 255.0f;
@@ -320,10 +320,12 @@ __global__ void crop_resize_bilinear_kernel(const uint8_t* src, uint8_t* dst, in
     for (int c = 0; c < 3; ++c) {
       const float p00 = (float)r0[x0 * 3 + c] * k, p01 = (float)r0[x1 * 3 + c] * k;
       const float p10 = (float)r1[x0 * 3 + c] * k, p11 = (float)r1[x1 * 3 + c] * k;
-      const float a0 = p00 * wx1, a1 = p01 * wx, b0 = p10 * wx1, b1 = p11 * wx;
-      const float top = a0 + a1, bot = b0 + b1;
-      const float t0 = top * wy1, t1 = bot * wy;
-      float v = t0 + t1;
+      const float dt = p01 - p00, db = p11 - p10;                  // TF's form: top = tl + (tr - tl)·x_lerp, …
+      const float et = dt * wx, eb = db * wx;
+      const float top = p00 + et, bot = p10 + eb;
+      const float dv = bot - top;
+      const float ev = dv * wy;
+      float v = top + ev;
       v = fminf(fmaxf(v, 0.0f), 1.0f);
       const float s = v * 255.5f;
       q[c] = (uint8_t)fminf(fmaxf(s, 0.0f), 255.0f);

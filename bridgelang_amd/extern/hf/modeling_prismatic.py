@@ -202,9 +202,12 @@ class PrismaticForConditionalGeneration(PrismaticPreTrainedModel):
             cache.move_to_end(key)
         return eng
 
-    def engine(self, batch: int, prompt_len: int, n_new: int = 7, padded: bool = False) -> OpenVLAEngine:
+    def engine(self, batch: int, prompt_len: int, n_new: int = 7, padded: bool = False, cached: bool = False) -> OpenVLAEngine:
+        """`cached=True`: the engine behind a `forward(..., use_cache=True)` KV-cache handle — keyed apart from the engines
+        `predict_action` / `generate` use, so an interleaved action prediction of the same shape does not invalidate the
+        caller's cache (each kind has its own LRU slot; a second cached prefill of the same shape still does)."""
         fp8 = bool(getattr(self, "fp8", False))       # `model.fp8 = True`: W8A8 e4m3 Llama prefill projections (extension)
-        return self._lru(self._engines, (batch, prompt_len, n_new, fp8, padded),
+        return self._lru(self._engines, (batch, prompt_len, n_new, fp8, padded, cached),
                          lambda: OpenVLAEngine(self.weights, batch, prompt_len, n_new=n_new, fp8=fp8 and not padded, padded=padded))
 
     # ---- forward: the reference's three branches (modeling_prismatic.py:322-415) ----

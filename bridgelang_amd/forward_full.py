@@ -127,7 +127,7 @@ def forward_prefill_cached(model, input_ids: torch.Tensor, attention_mask: Optio
     dev = model.device
     B, L = input_ids.shape
     padded = attention_mask is not None and not bool(attention_mask.bool().all())
-    eng = model.engine(B, L, max_new_tokens, padded=padded)
+    eng = model.engine(B, L, max_new_tokens, padded=padded, cached=True)
     if padded:
         eng.set_padded_inputs(input_ids.to(dev), pixel_values.to(dev), attention_mask)
     else:

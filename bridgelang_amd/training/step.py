@@ -319,9 +319,15 @@ class ParamStore:
         return _block_view(sl, pl).reshape(shape)
 
     def named_grad(self, name: str) -> torch.Tensor:
-        """Local (un-reduced) gradient under its HF name / shape (a copy for grouped tensors). For a parameter-sharded
-        decoder layer this reads the transient slot: meaningful only for the two layers whose backward ran last."""
-        return self._named(None, name, self._unit_grad(self.by_name[name]))
+        """Gradient under its HF name / shape (a copy for grouped tensors): the local, un-reduced gradient of a replicated
+        bucket. Parameter-sharded units have no such thing once collectives run — their full gradient lives in a transient
+        slot that the flush reduce-scatters in place and later units overwrite — so this raises for them; without
+        collectives (one rank) the rank's "slice" is the whole bucket and the call is valid."""
+        u = self.by_name[name]
+        if self.layout.buckets[u.bucket].key in self.sharded_keys and self.use_grad_slots:
+            raise RuntimeError(f"{name}: the full gradient of a parameter-sharded unit is transient (reduce-scattered in its slot, "
+                               "overwritten two units later); read store.reduced_grad(bucket) — this rank's reduced slice — instead")
+        return self._named(None, name, self._unit_grad(u))
 
     def full_master(self, comm: Optional[ShardComm] = None) -> torch.Tensor:
         """All fp32 masters in the flat layout (gathered over ranks when sharded) — checkpoints and tests."""

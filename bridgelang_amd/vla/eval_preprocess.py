@@ -8,8 +8,10 @@
     (as the RLDS dataset builder stores frames), Lanczos-3 antialiased resize, round, clip to uint8.
 
 The reference runs both through TensorFlow, which is absent here and on the GPU box: the arithmetic below restates the
-TF ops' documented definitions with numpy / Pillow (JPEG codec and Lanczos filter are Pillow's, TF's differ in rounding
-details) — PARITY UNPINNED against TF; the tests check the defining properties (geometry, identity cases, value ranges).
+TF ops' definitions with numpy / Pillow — the centre crop in the fp32 operation order of TF's own CPU kernel (box arithmetic
+of openvla_utils.py:101-115 on float32, `top + (bottom − top)·lerp` interpolation), so the only gap left to the reference
+pipeline is whether TF's build contracts multiply-adds; the JPEG codec and Lanczos filter are Pillow's (TF's differ in
+rounding details) — PARITY UNPINNED against TF; the tests check the defining properties (geometry, identity cases, ranges).
 Frames then go through `PrismaticImageProcessor` (bit-exact vs Pillow, on the CPU or on the GPU).
 
 Device twins for uint8 frames already in HBM (SURVEY §8(f)2 "as a GPU kernel (K1) fed by uint8 frames"):
@@ -36,25 +38,27 @@ def _to_uint8_saturate(img_f: np.ndarray) -> np.ndarray:
 
 
 def sampling_constants(box: Tuple[float, float, float, float], hw: Tuple[int, int], out_hw: Tuple[int, int]):
-    """The four fp32 constants of `crop_and_resize_bilinear`'s sampling grid: ys[i] = y_base + i·y_step (xs likewise),
-    each rounded to fp32 exactly where numpy rounds it (a python-float scalar meeting a float32 array)."""
-    (H, W), (oh, ow), (y1, x1, y2, x2) = hw, out_hw, box
-    f = lambda v: float(np.float32(v))
+    """The four fp32 constants of the sampling grid of TF's CropAndResize kernel: in_y = y1·(H-1) + i·height_scale with
+    height_scale = (y2 - y1)·(H-1) / (out_h - 1), every operation in fp32 in TF's order (crop_and_resize_op.cc); a single
+    output row / column samples the box centre."""
+    (H, W), (oh, ow), (y1, x1, y2, x2) = hw, out_hw, (np.float32(v) for v in box)
+    f32 = np.float32
     if oh == 1:
-        y_base, y_step = f(0.5 * (y1 + y2) * (H - 1)), 0.0
+        y_base, y_step = f32(0.5) * (y1 + y2) * f32(H - 1), f32(0.0)
     else:
-        y_base, y_step = f(y1 * (H - 1)), f((y2 - y1) * (H - 1) / max(oh - 1, 1))
+        y_base, y_step = y1 * f32(H - 1), (y2 - y1) * f32(H - 1) / f32(oh - 1)
     if ow == 1:
-        x_base, x_step = f(0.5 * (x1 + x2) * (W - 1)), 0.0
+        x_base, x_step = f32(0.5) * (x1 + x2) * f32(W - 1), f32(0.0)
     else:
-        x_base, x_step = f(x1 * (W - 1)), f((x2 - x1) * (W - 1) / max(ow - 1, 1))
-    return y_base, y_step, x_base, x_step
+        x_base, x_step = x1 * f32(W - 1), (x2 - x1) * f32(W - 1) / f32(ow - 1)
+    return float(y_base), float(y_step), float(x_base), float(x_step)
 
 
 def center_crop_box(crop_scale: float) -> Tuple[float, float, float, float]:
-    side = float(np.clip(np.sqrt(crop_scale), 0.0, 1.0))
-    off = (1.0 - side) / 2.0
-    return (off, off, off + side, off + side)
+    """openvla_utils.py:101-115 in the reference's own precision: tf.sqrt / clip / (1 - s) / 2 / offset + s on float32 tensors."""
+    side = np.clip(np.sqrt(np.float32(crop_scale)), np.float32(0.0), np.float32(1.0))
+    off = (np.float32(1.0) - side) / np.float32(2.0)
+    return (float(off), float(off), float(off + side), float(off + side))
 
 
 def center_crop_and_resize_gpu(frames_u8, crop_scale: float = 0.9, out_hw: Tuple[int, int] = (224, 224)):
@@ -75,25 +79,24 @@ def lanczos_resize_gpu(frames_u8, resize_size: Tuple[int, int]):
 
 
 def crop_and_resize_bilinear(img_f: np.ndarray, box: Tuple[float, float, float, float], out_hw: Tuple[int, int]) -> np.ndarray:
-    """tf.image.crop_and_resize for one image [H, W, C] float32 and one normalised box (y1, x1, y2, x2): output pixel
-    (i, j) samples the input at y = y1·(H-1) + i·(y2-y1)·(H-1)/(out_h-1) (likewise x), bilinear, 0 outside the image."""
+    """tf.image.crop_and_resize for one image [H, W, C] float32 and one normalised box (y1, x1, y2, x2), in the arithmetic of
+    TF's CPU kernel (crop_and_resize_op.cc): in_y = y_base + i·y_step (fp32), top / bottom = floor / ceil, lerp = in − floor,
+    top = tl + (tr − tl)·x_lerp, bottom = bl + (br − bl)·x_lerp, out = top + (bottom − top)·y_lerp — every operation rounded
+    to fp32 on its own; 0 (the extrapolation value) outside the image."""
     H, W, _ = img_f.shape
     oh, ow = out_hw
-    y1, x1, y2, x2 = box
-    ys = y1 * (H - 1) + np.arange(oh, dtype=np.float32) * ((y2 - y1) * (H - 1) / max(oh - 1, 1))
-    xs = x1 * (W - 1) + np.arange(ow, dtype=np.float32) * ((x2 - x1) * (W - 1) / max(ow - 1, 1))
-    if oh == 1:
-        ys = np.array([0.5 * (y1 + y2) * (H - 1)], dtype=np.float32)
-    if ow == 1:
-        xs = np.array([0.5 * (x1 + x2) * (W - 1)], dtype=np.float32)
-    y0, x0 = np.floor(ys).astype(np.int64), np.floor(xs).astype(np.int64)
-    wy, wx = (ys - y0).astype(np.float32)[:, None, None], (xs - x0).astype(np.float32)[None, :, None]
+    yb, ystep, xb, xstep = (np.float32(v) for v in sampling_constants(box, (H, W), out_hw))
+    ys = yb + np.arange(oh, dtype=np.float32) * ystep
+    xs = xb + np.arange(ow, dtype=np.float32) * xstep
     inside = ((ys >= 0) & (ys <= H - 1))[:, None, None] & ((xs >= 0) & (xs <= W - 1))[None, :, None]
-    y0c, y1c = np.clip(y0, 0, H - 1), np.clip(y0 + 1, 0, H - 1)
-    x0c, x1c = np.clip(x0, 0, W - 1), np.clip(x0 + 1, 0, W - 1)
-    top = img_f[y0c][:, x0c] * (1 - wx) + img_f[y0c][:, x1c] * wx
-    bot = img_f[y1c][:, x0c] * (1 - wx) + img_f[y1c][:, x1c] * wx
-    return np.where(inside, top * (1 - wy) + bot * wy, np.float32(0.0)).astype(np.float32)
+    yt, yl = np.floor(ys), np.floor(xs)
+    wy, wx = (ys - yt).astype(np.float32)[:, None, None], (xs - yl).astype(np.float32)[None, :, None]
+    y0c, y1c = np.clip(yt.astype(np.int64), 0, H - 1), np.clip(np.ceil(ys).astype(np.int64), 0, H - 1)
+    x0c, x1c = np.clip(yl.astype(np.int64), 0, W - 1), np.clip(np.ceil(xs).astype(np.int64), 0, W - 1)
+    tl, tr, bl, br = img_f[y0c][:, x0c], img_f[y0c][:, x1c], img_f[y1c][:, x0c], img_f[y1c][:, x1c]
+    top = tl + (tr - tl) * wx
+    bot = bl + (br - bl) * wx
+    return np.where(inside, top + (bot - top) * wy, np.float32(0.0)).astype(np.float32)
 
 
 def center_crop_and_resize(image_u8: np.ndarray, crop_scale: float = 0.9, out_hw: Tuple[int, int] = (224, 224)) -> np.ndarray:

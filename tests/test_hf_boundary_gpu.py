@@ -191,6 +191,11 @@ def test_forward_step_by_step_reproduces_generate(saved, dev):
     top2 = o1.logits[:, -1].topk(2, -1).values
     decisive = (top2[:, 0] - top2[:, 1]) > 0.05 * o1.logits.abs().max()
     assert torch.equal(o1.logits[:, -1].argmax(-1)[decisive], ref[decisive])
+    # an action prediction of the SAME shape in between leaves the caller's cache alone (cached-forward engines have their own slots)
+    held = model(input_ids=ids, pixel_values=pv, use_cache=True)
+    model.generate(ids, max_new_tokens=model.cache_new_tokens, pixel_values=pv)
+    again = model(input_ids=forced, past_key_values=held.past_key_values, use_cache=True)
+    assert torch.equal(again.logits, o1.logits)
     # guards: capacity, stale handles, missing cache
     with pytest.raises(AssertionError):
         model(input_ids=forced, use_cache=True)

@@ -351,11 +351,16 @@ def test_crop_sampling_constants_reproduce_the_host_grid():
         box = EP.center_crop_box(cs)
         yb, ys, xb, xs = EP.sampling_constants(box, (H, W), out_hw)
         oh, ow = out_hw
-        y1, x1, y2, x2 = box
-        want_y = y1 * (H - 1) + np.arange(oh, dtype=np.float32) * ((y2 - y1) * (H - 1) / max(oh - 1, 1))
-        want_x = x1 * (W - 1) + np.arange(ow, dtype=np.float32) * ((x2 - x1) * (W - 1) / max(ow - 1, 1))
+        f32 = np.float32
+        assert all(f32(v) == v for v in box), "the box is computed in fp32 (tf.sqrt / clip / offsets on float32 tensors)"
+        side = np.clip(np.sqrt(f32(cs)), f32(0), f32(1))
+        assert box == (float((f32(1) - side) / f32(2)),) * 2 + (float((f32(1) - side) / f32(2) + side),) * 2
+        y1, x1, y2, x2 = (f32(v) for v in box)
+        # TF's CropAndResize kernel: scale = (y2 - y1) * (H - 1) / (out - 1); in_y = y1 * (H - 1) + i * scale, all fp32
+        want_y = y1 * f32(H - 1) + np.arange(oh, dtype=np.float32) * ((y2 - y1) * f32(H - 1) / f32(max(oh - 1, 1)))
+        want_x = x1 * f32(W - 1) + np.arange(ow, dtype=np.float32) * ((x2 - x1) * f32(W - 1) / f32(max(ow - 1, 1)))
         if ow == 1:
-            want_x = np.array([0.5 * (x1 + x2) * (W - 1)], dtype=np.float32)
+            want_x = np.array([f32(0.5) * (x1 + x2) * f32(W - 1)], dtype=np.float32)
         got_y = np.float32(yb) + np.arange(oh, dtype=np.float32) * np.float32(ys)
         got_x = np.float32(xb) + np.arange(ow, dtype=np.float32) * np.float32(xs)
         assert np.array_equal(got_y, want_y) and np.array_equal(got_x, want_x)
