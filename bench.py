@@ -36,6 +36,19 @@ from pathlib import Path
 import torch
 
 ROOT = Path(__file__).resolve().parent
+
+
+def newest_pmc(name: str):
+    """The most recent committed PMC summary profiles/pmc_rNN*/<name> (bench.py cannot run rocprofv3 on itself: the traffic
+    figure it quotes is measured separately, and `traffic_source` says when and on which commit)."""
+    cands = sorted((ROOT / "profiles").glob(f"pmc_r*/{name}"), key=lambda q: q.parent.name)
+    return cands[-1] if cands else None
+
+
+def pmc_provenance(path, pj: dict) -> dict:
+    c = pj.get("collected") or {}
+    return {"file": str(path.relative_to(ROOT)), "collected_at_commit": c.get("commit"), "collected_on": c.get("date"),
+            "round": c.get("round"), "note": "GEMM kernels changed since that commit => re-run the --pmc passes (tools/pmc_gemm.py)"}
 sys.path.insert(0, str(ROOT))
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 (guides/MI355X_MICROARCH.md)
@@ -355,9 +368,11 @@ def train_line(args, rank: int, world: int, dev) -> dict:
         model_flops = sum(op.flops for op in plan)
         ms = elapsed / args.steps * 1e3
         train_traffic = None          # HBM bytes per forward GEMM call from the committed PMC passes (same M as this run only)
-        pmc = ROOT / "profiles" / "pmc_r03" / "gemm_traffic_train.json"
-        if pmc.exists() and args.model == "openvla-7b" and ts.T == 9472 and not args.fp8:
-            train_traffic = round(json.loads(pmc.read_text())["avg_hbm_bytes_per_call_llama_layer"])
+        pmc = newest_pmc("gemm_traffic_train.json")
+        pmc_src = None
+        if pmc is not None and args.model == "openvla-7b" and ts.T == 9472 and not args.fp8:
+            pj = json.loads(pmc.read_text())
+            train_traffic, pmc_src = round(pj["avg_hbm_bytes_per_call_llama_layer"]), pmc_provenance(pmc, pj)
         cfg_no = 4 if args.model == "prism-13b" else 3 if args.stage == "lora" else 2
         line = {
             "metric": f"samples/sec {dims.name} {args.stage} bf16", "value": round(world * B * args.steps / elapsed, 3), "unit": "samples/s",
@@ -377,8 +392,9 @@ def train_line(args, rank: int, world: int, dev) -> dict:
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": train_traffic,
                          "traffic_note": "avg HBM+Infinity-Cache bytes per forward bl_gemm_bf16 call over the 4 decoder-layer GEMM shapes at "
-                                         "M = 9472 token rows, separate --pmc passes (profiles/pmc_r03/gemm_traffic_train.json); dgrad / wgrad "
+                                         "M = 9472 token rows, separate --pmc passes (committed summary, see traffic_source); dgrad / wgrad "
                                          "launches of the family not counted" if train_traffic else None,
+                         "traffic_source": pmc_src,
                          "kernel": "tiled MFMA GEMM family per call: bl_gemm_bf16 (forward, dgrad), bl_gemm_tn_bf16 (wgrad)" + (", bl_gemm_fp8 (e4m3 forward / dgrad; priced against the bf16 peak)" if args.fp8 else ""),
                          "launches_per_step": gemm["launches"], "avg_launch_us": round(gemm["ms"] * 1e3 / gemm["launches"], 2),
                          "algorithmic_gflop_per_launch": round(gemm["flops"] / gemm["launches"] / 1e9, 3)},
@@ -510,10 +526,11 @@ def main() -> None:
         skinny = prof.get("bl_gemm_skinny_bf16")
         kern_ms = sum(a["ms"] for a in prof.values())
         traffic = None      # HBM bytes per GEMM call from the committed PMC passes (bench.py cannot run rocprofv3 itself)
-        pmc = next((q for q in (ROOT / "profiles" / d / "gemm_traffic.json" for d in ("pmc_r03", "pmc_r02_final")) if q.exists()),
-                   ROOT / "profiles" / "pmc_r03" / "gemm_traffic.json")
-        if pmc.exists() and args.model == "openvla-7b" and args.batch == 16 and args.prompt_len == 32 and not args.fp8:
-            traffic = round(json.loads(pmc.read_text())["avg_hbm_bytes_per_call_llama_layer"])
+        pmc = newest_pmc("gemm_traffic.json")
+        pmc_src = None
+        if pmc is not None and args.model == "openvla-7b" and args.batch == 16 and args.prompt_len == 32 and not args.fp8:
+            pj = json.loads(pmc.read_text())
+            traffic, pmc_src = round(pj["avg_hbm_bytes_per_call_llama_layer"]), pmc_provenance(pmc, pj)
         # algorithmic work per sequence: the SURVEY figure for the BASELINE model, the plan's own GEMM + attention FLOPs otherwise
         algo = ALGO_TFLOP_PER_SEQ if args.model == "openvla-7b" else sum(op.flops for op in eng.all_ops()) / args.batch / 1e12
         line = {
@@ -533,7 +550,9 @@ def main() -> None:
                        "replicas": world, "hip_graph": not args.no_graph, "pipeline_depth": args.pipeline},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "traffic_note": f"avg HBM+Infinity-Cache bytes per bl_gemm_bf16 call over the 4 Llama prefill GEMMs, separate --pmc passes (profiles/{pmc.parent.name}/gemm_traffic.json)",
+                         "traffic_note": "avg HBM+Infinity-Cache bytes per bl_gemm_bf16 call over the 4 Llama prefill GEMMs, separate --pmc passes: "
+                                         "read from a COMMITTED summary (bench.py cannot run rocprofv3 on itself), see traffic_source",
+                         "traffic_source": pmc_src,
                          "kernel": ("gemm256s_fp8_kernel (per bl_gemm_fp8 call)" if args.fp8 else
                                     "tiled MFMA GEMM family: gemm256s_kernel / gemm288s_kernel + gemm_tail_kernel (per bl_gemm_bf16 call)"), "launches_per_step": gemm["launches"],
                          "avg_launch_us": round(gemm["ms"] * 1e3 / gemm["launches"], 2),
