@@ -43,6 +43,13 @@ class GemmDesc(C.Structure):
     ]
 
 
+class BatchOpDesc(C.Structure):
+    """One entry of bl_batched_ops' device table (struct BatchOp in csrc/train.hip)."""
+    _fields_ = [("kind", C.c_int32), ("nblocks", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("rows_pad", C.c_int32),
+                ("bx_count", C.c_int32), ("ld", C.c_int64), ("kt_total", C.c_int64), ("kb_off", C.c_int64), ("n", C.c_int64),
+                ("src", C.c_void_p), ("dst", C.c_void_p), ("scale", C.c_float), ("pad", C.c_int32)]
+
+
 class AttnDesc(C.Structure):
     """struct bl_attn_desc."""
     _fields_ = [
@@ -116,6 +123,7 @@ SIGNATURES = {
     "bl_cast_bf16_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "bl_memset_zero": (C.c_int, [_vp, _i64, _vp]),
     "bl_copy_bytes": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "bl_batched_ops": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     "bl_map_rows_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "bl_embed_backward_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "bl_preprocess_u8_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),

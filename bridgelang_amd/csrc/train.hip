@@ -487,20 +487,29 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 __device__ __forceinline__ int tr_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
 
 template <bool PACKED>
-__global__ __launch_bounds__(256) void transpose_fast_kernel(const uint16_t* in, long ldi, int rows, int cols,
-                                                             uint16_t* out, long ldo, int rows_pad, long kt_total, long kb_off) {
+__device__ __forceinline__ void transpose_fast_body(char* tile, int bx, int by, const uint16_t* in, long ldi, int rows, int cols,
+                                                    uint16_t* out, long ldo, int rows_pad, long kt_total, long kb_off, float scale) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  __shared__ __attribute__((aligned(16))) char tile[256 * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   // column tiles vary fastest over the grid: workgroups running together read neighbouring 128-byte segments of the
   // same rows (whole DRAM bursts / pages) instead of isolated segments 256 rows apart
-  const int r0 = blockIdx.y * 256, c0 = blockIdx.x * 64;
+  const int r0 = by * 256, c0 = bx * 64;
   u32x4_t v[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int piece = tid + 256 * u, row = piece >> 3, ch = piece & 7;
     v[u] = (u32x4_t){0u, 0u, 0u, 0u};
     if (r0 + row < rows) v[u] = *(const u32x4_t*)(in + (long)(r0 + row) * ldi + c0 + ch * 8);
+  }
+  if (scale != 1.0f) {                       // bf16(s · x) — the arithmetic of bl_scale_bf16 (LoRA: s · B before it is packed)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float f[8];
+      unpack8(v[u], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] *= scale;
+      v[u] = pack8(f);
+    }
   }
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
@@ -528,6 +537,71 @@ __global__ __launch_bounds__(256) void transpose_fast_kernel(const uint16_t* in,
     }
   }
 #endif
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void transpose_fast_kernel(const uint16_t* in, long ldi, int rows, int cols,
+                                                             uint16_t* out, long ldo, int rows_pad, long kt_total, long kb_off) {
+  __shared__ __attribute__((aligned(16))) char tile[256 * 128];
+  transpose_fast_body<PACKED>(tile, blockIdx.x, blockIdx.y, in, ldi, rows, cols, out, ldo, rows_pad, kt_total, kb_off, 1.0f);
+}
+
+// ---- batched small ops (round 4): ONE launch for a table of independent copy / (scaled) pack / (scaled) transpose-pack ops.
+// The LoRA step re-packed its 330 adapters with five launches each and copied 660 updated tensors back one launch at a time
+// (≈ 2 300 launches of 3-5 µs behind ≈ 6 µs of launch gap each: 10 % of the step); the full fine-tune's re-pack plan is ≈ 800
+// launches. Each table entry owns a contiguous range of workgroups; a workgroup finds its entry by binary search over the
+// block prefix sums and runs the same device code as the stand-alone kernels (identical results).
+struct BatchOp {
+  int32_t kind, nblocks, rows, cols, rows_pad, bx_count;   // kind: 0 copy bytes (n = bytes), 1 pack [rows = n, cols = k], 2 transpose-pack
+  int64_t ld, kt_total, kb_off, n;
+  const void* src;
+  void* dst;
+  float scale;
+  int32_t pad;
+};
+
+__global__ __launch_bounds__(256) void batched_ops_kernel(const BatchOp* ops, const int32_t* block_start, int n_ops) {
+  __shared__ __attribute__((aligned(16))) char tile[256 * 128];
+  int lo = 0, hi = n_ops - 1;                                  // last entry whose first block is <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (block_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const BatchOp op = ops[lo];
+  const long lb = (long)blockIdx.x - block_start[lo], nb = op.nblocks;
+  if (op.kind == 0) {                                          // bl_copy_bytes
+    const long n16 = op.n >> 4;
+    const u32x4_t* s4 = (const u32x4_t*)op.src;
+    u32x4_t* d4 = (u32x4_t*)op.dst;
+    const bool vec = (((uintptr_t)op.src | (uintptr_t)op.dst) & 15) == 0;
+    if (vec) {
+      for (long i = lb * 256 + threadIdx.x; i < n16; i += nb * 256) d4[i] = s4[i];
+      for (long i = (n16 << 4) + lb * 256 + threadIdx.x; i < op.n; i += nb * 256) ((uint8_t*)op.dst)[i] = ((const uint8_t*)op.src)[i];
+    } else {
+      for (long i = lb * 256 + threadIdx.x; i < op.n; i += nb * 256) ((uint8_t*)op.dst)[i] = ((const uint8_t*)op.src)[i];
+    }
+  } else if (op.kind == 1) {                                   // bl_pack_weight(_into)_bf16, optionally bf16(s · x) first
+    const uint16_t* src = (const uint16_t*)op.src;
+    uint16_t* dst = (uint16_t*)op.dst;
+    const long n = op.rows, k = op.cols, ks_n = k >> 5, total = (n >> 4) * ks_n * 64;
+    for (long i = lb * 256 + threadIdx.x; i < total; i += nb * 256) {
+      const int lane = (int)(i & 63);
+      const long blk = i >> 6, ks = blk % ks_n, nt = blk / ks_n;
+      const long row = nt * 16 + (lane & 15), col = ks * 32 + (lane >> 4) * 8;
+      u32x4_t v = *(const u32x4_t*)(src + row * op.ld + col);
+      if (op.scale != 1.0f) {
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= op.scale;
+        v = pack8(f);
+      }
+      *(u32x4_t*)(dst + ((nt * op.kt_total + op.kb_off + ks) * 64 + lane) * 8) = v;
+    }
+  } else {                                                     // bl_transpose_pack(_into)_bf16
+    transpose_fast_body<true>(tile, (int)(lb % op.bx_count), (int)(lb / op.bx_count), (const uint16_t*)op.src, op.ld, op.rows, op.cols,
+                              (uint16_t*)op.dst, 0L, op.rows_pad, op.kt_total, op.kb_off, op.scale);
+  }
 }
 
 // ---- small-output TN GEMM:  C = Pᵀ·Q  with P [T, R] (R ∈ {64, 128, 192}: a LoRA rank block) and Q [T, N] (N % 64 == 0),
@@ -1057,6 +1131,14 @@ extern "C" int bl_embed_backward_bf16(const int64_t* ids, int32_t B, int32_t L, 
   if (B <= 0 || L <= 0 || dim <= 0 || (dim % 8) || n_patches < 0) return BL_E_SHAPE;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((long)B * L * (dim / 8), 256)), dim3(256), 0, (hipStream_t)stream,
                      ids, B, L, dx, dim, n_patches, dw);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_batched_ops(const void* ops_table, const int32_t* block_start, int32_t n_ops, int32_t total_blocks, void* stream) {
+  if (!ops_table || !block_start) return BL_E_ARG;
+  if (n_ops <= 0 || total_blocks <= 0) return BL_E_SHAPE;
+  hipLaunchKernelGGL(batched_ops_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const BatchOp*)ops_table, block_start, n_ops);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

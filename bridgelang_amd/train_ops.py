@@ -274,6 +274,65 @@ def transpose_pack_into(a: torch.Tensor, out: torch.Tensor, rows_pad: int, kt_to
                                                rows_pad, kt_total, kb_offset), (a, out), run, nbytes=2.0 * cols * (rows + rows_pad))
 
 
+# ---- batched small ops: one launch for a table of independent copies / (scaled) packs / (scaled) transposing packs -------------
+def _grid_for(total: int, block: int = 256) -> int:
+    return max(1, min(2048, (total + block - 1) // block))
+
+
+def be_copy(src: torch.Tensor, dst: torch.Tensor):
+    """Table entry: dst ← src (bytes), the work of bl_copy_bytes."""
+    from ._lib import BatchOpDesc
+    assert src.is_contiguous() and dst.is_contiguous() and src.numel() * src.element_size() == dst.numel() * dst.element_size()
+    n = src.numel() * src.element_size()
+    vec = ((src.data_ptr() | dst.data_ptr()) & 15) == 0
+    d = BatchOpDesc(kind=0, nblocks=_grid_for((n + 15) // 16 if vec else n), n=n, src=src.data_ptr(), dst=dst.data_ptr(), scale=1.0)
+    return d, (src, dst)
+
+
+def be_pack(w: torch.Tensor, out: torch.Tensor, kt_total: Optional[int] = None, kb_offset: int = 0, scale: float = 1.0):
+    """Table entry: row-major [N, K] → k-blocks [kb_offset, …) of packed `out` (bl_pack_weight(_into)_bf16), of bf16(scale · w)."""
+    from ._lib import BatchOpDesc
+    N, K = w.shape
+    kt = K // 32 if kt_total is None else kt_total
+    assert N % 16 == 0 and K % 32 == 0 and out.numel() == N * kt * 32 and kb_offset + K // 32 <= kt and w.stride(1) == 1
+    d = BatchOpDesc(kind=1, nblocks=_grid_for(N * K // 8), rows=N, cols=K, ld=w.stride(0), kt_total=kt, kb_off=kb_offset,
+                    src=_bf16(w, "w").data_ptr(), dst=_bf16(out, "out").data_ptr(), scale=float(scale))
+    return d, (w, out)
+
+
+def be_transpose_pack(a: torch.Tensor, out: torch.Tensor, rows_pad: int, kt_total: Optional[int] = None, kb_offset: int = 0,
+                      scale: float = 1.0):
+    """Table entry: [rows, cols] → the transposed matrix's k-blocks of packed `out` (bl_transpose_pack(_into)_bf16), of bf16(scale · a)."""
+    from ._lib import BatchOpDesc
+    rows, cols = a.shape
+    kt = rows_pad // 32 if kt_total is None else kt_total
+    assert cols % 64 == 0 and rows_pad % 32 == 0 and rows_pad >= rows and out.numel() == cols * kt * 32 and a.stride(1) == 1
+    bx = cols // 64
+    d = BatchOpDesc(kind=2, nblocks=bx * ((rows_pad + 255) // 256), rows=rows, cols=cols, rows_pad=rows_pad, bx_count=bx,
+                    ld=a.stride(0), kt_total=kt, kb_off=kb_offset, src=_bf16(a, "a").data_ptr(), dst=_bf16(out, "out").data_ptr(),
+                    scale=float(scale))
+    return d, (a, out)
+
+
+def batched(entries, device, run: bool = True) -> Op:
+    """ONE launch (bl_batched_ops) for the table entries made by be_copy / be_pack / be_transpose_pack. The entries must be
+    independent of each other (no entry reads what another one writes)."""
+    import ctypes as C
+    import numpy as np
+    from ._lib import BatchOpDesc
+    descs = [e[0] for e in entries]
+    arr = (BatchOpDesc * len(descs))(*descs)
+    table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(device)
+    starts, tot = [], 0
+    for d in descs:
+        starts.append(tot)
+        tot += d.nblocks
+    block_start = torch.tensor(starts, dtype=torch.int32, device=device)
+    keep = tuple(t for e in entries for t in e[1])
+    nbytes = float(sum((d.n if d.kind == 0 else 2 * d.rows * d.cols) * 2 for d in descs))
+    return _op("bl_batched_ops", (table.data_ptr(), block_start.data_ptr(), len(descs), tot), (table, block_start) + keep, run, nbytes=nbytes)
+
+
 def cast(src: torch.Tensor, dst: torch.Tensor, run: bool = True) -> Op:
     """fp32 → bf16 (round to nearest even) or bf16 → fp32 of flat contiguous buffers (gradient wire format)."""
     assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()

@@ -298,6 +298,14 @@ int bl_pack_weight_into_bf16(const bl_bf16* w, int64_t ldw, int64_t N, int64_t K
                              int64_t kb_offset, void* stream);
 int bl_transpose_pack_into_bf16(const bl_bf16* in, int64_t ld_in, int32_t rows, int32_t cols, bl_bf16* out_packed,
                                 int32_t rows_pad, int64_t kt_total, int64_t kb_offset, void* stream);
+/* ONE launch for a table of independent small ops — copies, (scaled) packs, (scaled) transposing packs: the re-pack plan of a
+ * training step (every LoRA adapter's five refresh launches, the optimizer's write-backs). ops_table: device array of
+ *   struct { int32 kind, nblocks, rows, cols, rows_pad, bx_count; int64 ld, kt_total, kb_off, n; const void* src; void* dst;
+ *            float scale; int32 pad; }        (kind 0: copy n bytes; 1: pack rows x cols into k-blocks [kb_off, ...) of a packed
+ *   matrix with kt_total k-blocks per 16-row tile; 2: transposing pack of [rows, cols], rows padded to rows_pad; scale != 1:
+ *   bf16(scale * x) first), block_start: device int32 [n_ops] prefix sums of nblocks. Same device code, same results, as
+ * bl_copy_bytes / bl_pack_weight_into_bf16 / bl_transpose_pack_into_bf16 (+ bl_scale_bf16). */
+int bl_batched_ops(const void* ops_table, const int32_t* block_start, int32_t n_ops, int32_t total_blocks, void* stream);
 /* Global gradient norm (fsdp.py:268-270): per-tensor partial sums of squares, then norm and clip coefficient
  * out_norm_coef = {||g||, min(1, max_norm / (||g|| + 1e-6))} (torch.nn.utils.clip_grad_norm_). */
 int bl_sumsq_partial_f32(const float* g, int64_t n, float* partial, int32_t nblocks, void* stream);
