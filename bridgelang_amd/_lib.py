@@ -124,6 +124,8 @@ SIGNATURES = {
     "bl_memset_zero": (C.c_int, [_vp, _i64, _vp]),
     "bl_copy_bytes": (C.c_int, [_vp, _vp, _i64, _vp]),
     "bl_batched_ops": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "bl_dropout_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _f32, _vp, _u32, _vp, _i64, _vp]),
+    "bl_dropout_grad_fix_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _f32, _vp, _u32, _vp, _i64, _vp]),
     "bl_map_rows_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "bl_embed_backward_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "bl_preprocess_u8_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),

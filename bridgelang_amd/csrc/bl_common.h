@@ -61,6 +61,12 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
+// integer hash shared by the synthetic-weight generator (glue.hip) and the dropout masks (train.hip); oracle/synth.py::_mix32
+__device__ __forceinline__ uint32_t bl_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+
 // ---- launch helpers -------------------------------------------------------------------------------------------
 #define BL_CHECK_LAUNCH()                                   \
   do {                                                      \

@@ -393,6 +393,50 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const uint16_t* dy,
   for (int e = 0; e < 8; ++e) partial[(long)blockIdx.x * cols + col8 + e] = acc[e];
 }
 
+// ---- LoRA dropout (PEFT: result = base(x) + lora_B(lora_A(dropout(x))) · scaling; vla-scripts/finetune.py:101,177) ----
+// Counter-based mask, recomputable in the backward pass: element (row, col) of the adapted linear `salt` is KEPT at step
+// *seed iff the top 24 bits of mix32(idx ^ mix32(mix32(*seed) + salt)) reach p · 2^24 (oracle/synth.py::dropout_keep restates
+// it). The seed lives on the device so that a captured plan draws a fresh mask on every replay.
+__device__ __forceinline__ bool drop_keep(uint32_t key, uint32_t idx, uint32_t thr) { return (bl_mix32(idx ^ key) >> 8) >= thr; }
+
+// out = bf16(x / (1 - p)) where kept, 0 elsewhere (nn.Dropout in training mode on a bf16 tensor)
+__global__ void dropout_kernel(const uint16_t* x, long ldx, int rows, int cols, uint32_t thr, float inv_keep, const uint32_t* seed,
+                               uint32_t salt, uint16_t* out, long ldo) {
+  const uint32_t key = bl_mix32(bl_mix32(*seed) + salt);
+  const int cpr = cols >> 3;
+  const long total = (long)rows * cpr;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long r = t / cpr;
+    const int c = (int)(t - r * cpr) * 8;
+    float v[8];
+    unpack8(*(const u32x4_t*)(x + r * ldx + c), v);
+    const uint32_t idx0 = (uint32_t)(r * cols + c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = drop_keep(key, idx0 + i, thr) ? v[i] * inv_keep : 0.f;
+    *(u32x4_t*)(out + r * ldo + c) = pack8(v);
+  }
+}
+// The single extended input-gradient GEMM gives dx = dy·W + u with u = dt·A (un-masked); dropout's backward wants dy·W + m̃ ⊙ u:
+// dx ← bf16(dx + bf16((1 / (1 - p) - 1) · u)) where kept, bf16(dx - u) where dropped
+__global__ void dropout_grad_fix_kernel(const uint16_t* u, long ldu, int rows, int cols, uint32_t thr, float inv_keep,
+                                        const uint32_t* seed, uint32_t salt, uint16_t* dx, long lddx) {
+  const uint32_t key = bl_mix32(bl_mix32(*seed) + salt);
+  const int cpr = cols >> 3;
+  const long total = (long)rows * cpr;
+  const float kf = inv_keep - 1.0f;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long r = t / cpr;
+    const int c = (int)(t - r * cpr) * 8;
+    float a[8], d[8];
+    unpack8(*(const u32x4_t*)(u + r * ldu + c), a);
+    unpack8(*(const u32x4_t*)(dx + r * lddx + c), d);
+    const uint32_t idx0 = (uint32_t)(r * cols + c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] += drop_keep(key, idx0 + i, thr) ? rbf(a[i] * kf) : -a[i];
+    *(u32x4_t*)(dx + r * lddx + c) = pack8(d);
+  }
+}
+
 // ---- LoRA helpers (vla-scripts/finetune.py:174-189) ----
 // out = bf16(s · x) on a small [T, R] tensor (the scaling alpha / r applied once to t and to dt)
 __global__ void scale_bf16_kernel(const uint16_t* x, float s, uint16_t* out, long n8) {
@@ -1139,6 +1183,36 @@ extern "C" int bl_batched_ops(const void* ops_table, const int32_t* block_start,
   if (!ops_table || !block_start) return BL_E_ARG;
   if (n_ops <= 0 || total_blocks <= 0) return BL_E_SHAPE;
   hipLaunchKernelGGL(batched_ops_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const BatchOp*)ops_table, block_start, n_ops);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+static int dropout_args_ok(const void* a, const void* b, const void* seed, int32_t rows, int32_t cols, float p, int64_t lda, int64_t ldb) {
+  if (!a || !b || !seed) return BL_E_ARG;
+  if (rows <= 0 || cols <= 0 || (cols % 8) || (lda % 8) || (ldb % 8) || lda < cols || ldb < cols || (long)rows * cols > 0xffffffffL) return BL_E_SHAPE;
+  if (!(p >= 0.f && p < 1.f)) return BL_E_ARG;
+  if (!bl_aligned16(a) || !bl_aligned16(b)) return BL_E_ALIGN;
+  return BL_OK;
+}
+
+extern "C" int bl_dropout_bf16(const bl_bf16* x, int64_t ldx, int32_t rows, int32_t cols, float p, const uint32_t* seed, uint32_t salt,
+                               bl_bf16* out, int64_t ldo, void* stream) {
+  const int rc = dropout_args_ok(x, out, seed, rows, cols, p, ldx, ldo);
+  if (rc != BL_OK) return rc;
+  const uint32_t thr = (uint32_t)lrintf(p * 16777216.0f);
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for((long)rows * (cols / 8), 256)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, rows,
+                     cols, thr, 1.0f / (1.0f - p), seed, salt, out, (long)ldo);
+  BL_CHECK_LAUNCH();
+  return BL_OK;
+}
+
+extern "C" int bl_dropout_grad_fix_bf16(const bl_bf16* u, int64_t ldu, int32_t rows, int32_t cols, float p, const uint32_t* seed,
+                                        uint32_t salt, bl_bf16* dx, int64_t lddx, void* stream) {
+  const int rc = dropout_args_ok(u, dx, seed, rows, cols, p, ldu, lddx);
+  if (rc != BL_OK) return rc;
+  const uint32_t thr = (uint32_t)lrintf(p * 16777216.0f);
+  hipLaunchKernelGGL(dropout_grad_fix_kernel, dim3(grid_for((long)rows * (cols / 8), 256)), dim3(256), 0, (hipStream_t)stream, u, (long)ldu,
+                     rows, cols, thr, 1.0f / (1.0f - p), seed, salt, dx, (long)lddx);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }

@@ -212,6 +212,22 @@ def scale(x: torch.Tensor, s: float, out: torch.Tensor, run: bool = True) -> Op:
     return _op("bl_scale_bf16", (_bf16(x, "x").data_ptr(), float(s), _bf16(out, "out").data_ptr(), x.numel()), (x, out), run)
 
 
+def dropout(x: torch.Tensor, out: torch.Tensor, p: float, seed: torch.Tensor, salt: int, run: bool = True) -> Op:
+    """out = nn.Dropout(p)(x) in training mode with the counter-based mask of (seed tensor [1] uint32 on the device, salt)."""
+    rows, cols = x.shape
+    assert seed.dtype in (torch.int32, torch.uint32) and seed.is_cuda and seed.numel() == 1
+    return _op("bl_dropout_bf16", (_bf16(x, "x").data_ptr(), _rows(x, "x"), rows, cols, float(p), seed.data_ptr(), int(salt) & 0xFFFFFFFF,
+                                   _bf16(out, "out").data_ptr(), _rows(out, "out")), (x, out, seed), run, nbytes=4.0 * rows * cols)
+
+
+def dropout_grad_fix(u: torch.Tensor, dx: torch.Tensor, p: float, seed: torch.Tensor, salt: int, run: bool = True) -> Op:
+    """dx (= dy·W + u) → dy·W + mask/(1-p) ⊙ u with the mask of `dropout(…, seed, salt)`."""
+    rows, cols = u.shape
+    return _op("bl_dropout_grad_fix_bf16", (_bf16(u, "u").data_ptr(), _rows(u, "u"), rows, cols, float(p), seed.data_ptr(),
+                                            int(salt) & 0xFFFFFFFF, _bf16(dx, "dx").data_ptr(), _rows(dx, "dx")), (u, dx, seed), run,
+               nbytes=6.0 * rows * cols)
+
+
 def lora_block_mask(g: torch.Tensor, rp: int, members: int, interleave: bool, run: bool = True) -> Op:
     n, R = g.shape
     assert g.is_contiguous()

@@ -42,11 +42,9 @@ def finetune(vlm, dataloader: Iterable[Dict[str, Any]], action_tokenizer, cfg: F
     cfg.batch_size samples. Returns the last smoothed metrics and the paths written."""
     if cfg.use_quantization:
         raise NotImplementedError("4-bit base weights (bitsandbytes) are outside the MI355X path: 288 GB HBM holds bf16")
-    if cfg.lora_dropout != 0.0:
-        raise NotImplementedError("lora_dropout != 0 (reference default 0.0)")
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
     w = vlm.weights
-    lora = LoraAdapters(w, r=cfg.lora_rank) if cfg.use_lora else None
+    lora = LoraAdapters(w, r=cfg.lora_rank, dropout=cfg.lora_dropout) if cfg.use_lora else None
     stage = "lora" if cfg.use_lora else "vla-full-train"
     engine: Optional[TrainStep] = None
     store = None

@@ -16,6 +16,9 @@ half an ulp of the base output (right after initialisation, B ≈ 0, PEFT's orde
 bf16(s·B) (exact for the reference's s = 0.5).
 Backward: dt = dy·(s·B) into spare columns of dy's buffer, dx = [dy | dt]·[Wᵀ | Aᵀ]ᵀ as one GEMM; dB = (s·tᵀ·dy)ᵀ and
 dA = dtᵀ·x through the small-output TN GEMM (bl_gemm_tn_small_bf16: dy / x read once, untransposed).
+`lora_dropout` = p > 0 (round 4): t = dropout(x)·Aᵀ from a masked copy of x (bl_dropout_bf16: counter-based mask, recomputed in
+the backward pass), dA = dtᵀ·dropout(x), and the fused input gradient dy·W + dt·A is corrected to dy·W + mask/(1-p) ⊙ (dt·A)
+with u = dt·A from one more rank-R GEMM (bl_dropout_grad_fix_bf16). p = 0 plans are unchanged.
 """
 from __future__ import annotations
 
@@ -59,10 +62,16 @@ class Adapter:
 class LoraAdapters:
     """All adapters of a model + their PEFT-named state dict."""
 
-    def __init__(self, w: VLAWeights, r: int = 32, alpha: Optional[int] = None, seed: int = 0):
+    def __init__(self, w: VLAWeights, r: int = 32, alpha: Optional[int] = None, seed: int = 0, dropout: float = 0.0):
+        """`dropout` = PEFT's `lora_dropout` (finetune.py:101,177): in training the adapter branch sees nn.Dropout(p)(x). One mask
+        per adapted GEMM and step: PEFT draws an independent mask for every module, here the modules fused into one GEMM
+        (q / k / v; gate / up) share theirs — each module's own statistics are PEFT's, only the correlation between the
+        fused modules' masks differs (training/step.py::_lin)."""
         if r > RP:
             raise ValueError(f"LoRA rank {r} exceeds the padded rank {RP}")
-        self.w, self.r = w, r
+        if not (0.0 <= dropout < 1.0):
+            raise ValueError(f"lora_dropout {dropout} outside [0, 1)")
+        self.w, self.r, self.dropout = w, r, float(dropout)
         self.alpha = min(r, 16) if alpha is None else alpha
         self.scaling = self.alpha / r
         dev = w.embed.device

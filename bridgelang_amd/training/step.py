@@ -951,6 +951,12 @@ class TrainStep:
         dev = self.device
         zb = lambda *shape: torch.zeros(*shape, dtype=torch.bfloat16, device=dev)
         entries = []
+        self._ATp: Dict[int, torch.Tensor] = {}                             # packed Aᵀ [k, R]: the u = dt·A operand (lora_dropout > 0)
+        if lora.dropout > 0.0:
+            rows = max([self.T, self.B * 256] + [self.B * tw.dims.tokens for tw in (self.w.dino, self.w.siglip)])
+            kmax = max(ad.group.k for ad in lora.adapters)
+            self._xd, self._ud = zb(rows, kmax), zb(rows, kmax)            # dropout(x) and u = dt·A of ONE adapted linear at a time
+            self._drop_seed = torch.zeros(1, dtype=torch.int32, device=dev)     # bumped once per forward pass
         for ad in lora.adapters:
             packed, n, k, R = ad.group.packed, ad.group.n, ad.group.k, ad.R
             KT, NT = (k + R) // 32, (n + R) // 32
@@ -964,6 +970,9 @@ class TrainStep:
             # entries of ONE bl_batched_ops launch for all adapters (rounds 1-3: five launches per adapter, 1 650 per step)
             entries += [T.be_pack(ad.B, We, KT, k // 32, scale=s), T.be_transpose_pack(ad.B, BsT, n, scale=s),
                         T.be_pack(ad.A, ad.A_p), T.be_transpose_pack(ad.A, WTe, R, NT, n // 32)]
+            if lora.dropout > 0.0:
+                self._ATp[key] = zb(k // 16, R // 32, 64, 8)
+                entries.append(T.be_transpose_pack(ad.A, self._ATp[key], R))
         self._adapter_ops = [T.batched(entries, dev, run=False)]
         ops.run_all(self._adapter_ops)
 
@@ -983,7 +992,12 @@ class TrainStep:
         assert wide.shape[1] >= K + R, "input buffer of an adapted linear lacks the adapter columns"
         t = wide[:, K:K + R]
         self._lora_t[packed.data_ptr()] = t
-        return [self._g(x, ad.A_p, t, EPI_NONE), self._g(wide[:, :K + R], self._Wext[packed.data_ptr()], out, epilogue, **kw)]
+        pre: List[Op] = []
+        xa = x
+        if self.lora.dropout > 0.0:            # PEFT: lora_A(dropout(x)); the base product below still reads the un-masked x
+            xa = self._xd[:x.shape[0], :K]
+            pre = [T.dropout(x, xa, self.lora.dropout, self._drop_seed, ad.index, run=False)]
+        return pre + [self._g(xa, ad.A_p, t, EPI_NONE), self._g(wide[:, :K + R], self._Wext[packed.data_ptr()], out, epilogue, **kw)]
 
     def _lin_bwd(self, dy: torch.Tensor, x: torch.Tensor, packed: torch.Tensor, dx: Optional[torch.Tensor],
                  epilogue: int = EPI_NONE, **kw) -> List[Op]:
@@ -1012,9 +1026,18 @@ class TrainStep:
         plan = [self._g(dy, self._BsT[key], dt, EPI_NONE), T.gemm_tn_small(t, dy, gB, True, self.tn_ws, alpha=s, run=False)]
         if len(ad.modules) > 1:
             plan.append(T.lora_block_mask(gB, R // len(ad.modules), len(ad.modules), ad.mode == "interleave", run=False))
-        plan.append(T.gemm_tn_small(dt, x, gA, False, self.tn_ws, run=False))
+        p = self.lora.dropout
+        xa = x
+        if p > 0.0:                            # the mask of the forward pass, recomputed (same device seed, same salt)
+            xa = self._xd[:x.shape[0], :x.shape[1]]
+            plan.append(T.dropout(x, xa, p, self._drop_seed, ad.index, run=False))
+        plan.append(T.gemm_tn_small(dt, xa, gA, False, self.tn_ws, run=False))
         if dx is not None:
             plan.append(self._g(wide[:, :N + R], self._WText[key], dx, epilogue, **kw))
+            if p > 0.0:                        # dx = dy·W + dt·A so far; dropout's backward masks the adapter's share
+                assert epilogue == EPI_NONE, "activation-backward epilogues are not combined with lora_dropout"
+                u = self._ud[:x.shape[0], :x.shape[1]]
+                plan += [self._g(dt, self._ATp[key], u, EPI_NONE), T.dropout_grad_fix(u, dx, p, self._drop_seed, ad.index, run=False)]
         return plan
 
     def _lin_act(self, x, packed, pre, act, kind: str, **kw) -> List[Op]:
@@ -1415,6 +1438,8 @@ class TrainStep:
 
     def forward(self, graph: bool = False) -> torch.Tensor:
         """Vision towers (frozen) → projector → decoder → loss. Returns the device scalar loss."""
+        if self.lora is not None and self.lora.dropout > 0.0:
+            self._drop_seed.add_(1)            # a fresh mask per forward pass; the backward pass recomputes it from the same value
         if self.train_vision:
             self._replay("vfwd", self.vision_forward_ops, graph)
         else:

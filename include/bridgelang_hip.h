@@ -306,6 +306,15 @@ int bl_transpose_pack_into_bf16(const bl_bf16* in, int64_t ld_in, int32_t rows, 
  *   bf16(scale * x) first), block_start: device int32 [n_ops] prefix sums of nblocks. Same device code, same results, as
  * bl_copy_bytes / bl_pack_weight_into_bf16 / bl_transpose_pack_into_bf16 (+ bl_scale_bf16). */
 int bl_batched_ops(const void* ops_table, const int32_t* block_start, int32_t n_ops, int32_t total_blocks, void* stream);
+/* LoRA dropout (PEFT: base(x) + lora_B(lora_A(dropout(x))) * scaling; vla-scripts/finetune.py:101,177 `lora_dropout`).
+ * bl_dropout_bf16: out = bf16(x / (1 - p)) where kept, 0 elsewhere; element (row, col) is kept iff the top 24 bits of
+ * mix32((row * cols + col) ^ mix32(mix32(*seed) + salt)) >= p * 2^24 (seed on the DEVICE: a replayed plan draws a new mask when the
+ * host bumps it; salt = the adapted linear). bl_dropout_grad_fix_bf16: turns the fused input gradient dx = dy.W + u (u = dt.A,
+ * un-masked) into dy.W + mask/(1-p) * u with the same mask: dx += (1/(1-p) - 1) * u where kept, dx -= u where dropped. */
+int bl_dropout_bf16(const bl_bf16* x, int64_t ldx, int32_t rows, int32_t cols, float p, const uint32_t* seed, uint32_t salt,
+                    bl_bf16* out, int64_t ldo, void* stream);
+int bl_dropout_grad_fix_bf16(const bl_bf16* u, int64_t ldu, int32_t rows, int32_t cols, float p, const uint32_t* seed, uint32_t salt,
+                             bl_bf16* dx, int64_t lddx, void* stream);
 /* Global gradient norm (fsdp.py:268-270): per-tensor partial sums of squares, then norm and clip coefficient
  * out_norm_coef = {||g||, min(1, max_norm / (||g|| + 1e-6))} (torch.nn.utils.clip_grad_norm_). */
 int bl_sumsq_partial_f32(const float* g, int64_t n, float* partial, int32_t nblocks, void* stream);

@@ -96,3 +96,13 @@ def synth_state_dict(specs: Iterable, seed: int = 0, overlays: Iterable = ()) ->
         if ov.base in sd:
             sd[ov.base][ov.row0:ov.row0 + ov.shape[0]] = synth_bf16(tuple(ov.shape), tensor_seed(ov.name, seed), ov.mean, ov.std)
     return sd
+
+
+def dropout_keep(seed: int, salt: int, rows: int, cols: int, p: float) -> np.ndarray:
+    """The keep mask [rows, cols] (bool) of bl_dropout_bf16 for device seed value `seed` and adapted linear `salt`:
+    kept iff the top 24 bits of mix32((row·cols + col) ^ mix32(mix32(seed) + salt)) >= round(p · 2^24). Test infrastructure."""
+    key = _mix32((_mix32(np.array([seed & 0xFFFFFFFF], dtype=np.uint64)) + np.uint64(salt & 0xFFFFFFFF)) & _M32)[0]
+    idx = np.arange(rows * cols, dtype=np.uint64)
+    h = _mix32(idx ^ key)
+    thr = np.uint64(int(np.rint(np.float32(p) * np.float32(16777216.0))))
+    return ((h >> np.uint64(8)) >= thr).reshape(rows, cols)

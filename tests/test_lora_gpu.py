@@ -188,3 +188,94 @@ def test_gradient_accumulation_equals_one_big_batch(dev):
     rel = ((grads["big"] - grads["accum"]).norm() / grads["big"].norm()).item()
     print(f"accumulated vs big batch: cosine {c:.6f}, rel diff {rel:.4f}")
     assert c > 0.999 and rel < 0.03
+
+
+def test_lora_dropout_step_is_consistent(dev):
+    """`lora_dropout` > 0 (vla-scripts/finetune.py:101,177; PEFT: base(x) + lora_B(lora_A(dropout(x)))·scaling). The oracle has
+    no per-module hook for a masked adapter branch, so the step is checked through properties on the tiny model with random
+    non-zero adapters: (i) p = 0 leaves the plans untouched; (ii) the mask changes the loss, and a new forward pass draws a new
+    mask; (iii) with the mask held fixed, a step −ε·g along the adapter gradient lowers the loss by ε·‖g‖² to first order —
+    forward (masked t), dB, dA (from the recomputed mask) and the masked share of dx are one consistent derivative."""
+    from bridgelang_amd import ops
+    from bridgelang_amd.training.lora import LoraAdapters
+    from bridgelang_amd.training.step import TrainStep
+    from bridgelang_amd.weights import allocate, tiny_dims
+    dims = tiny_dims()
+    w = allocate(dims, dev).fill_synthetic(seed=3)
+    B, L = 3, 20
+    ids, mask, labels, pv = make_batch(dims, B, L)
+
+    def build(p):
+        lora = LoraAdapters(w, r=32, dropout=p)
+        lora.load_state_dict(random_adapters(lora, seed=7, b_std=0.05))
+        ts = TrainStep(w, "lora", B, L, lora=lora, max_grad_norm=float("inf"), weight_decay=0.0)
+        ts.set_batch(ids, mask, pv, labels)
+        return lora, ts
+    lora0, ts0 = build(0.0)
+    names0 = [op.name for op in ts0.forward_ops + ts0.backward_ops]
+    assert "bl_dropout_bf16" not in names0 and "bl_dropout_grad_fix_bf16" not in names0
+    base_loss = ts0.forward().item()
+    del ts0, lora0
+    lora, ts = build(0.25)
+    names = [op.name for op in ts.vision_forward_ops + ts.forward_ops + ts.backward_ops]
+    n_ad = len(lora.adapters)
+    assert names.count("bl_dropout_bf16") == 2 * n_ad and names.count("bl_dropout_grad_fix_bf16") >= n_ad - 2
+    l1 = ts.forward().item()
+    l2 = ts.forward().item()                                       # the seed moved on: another mask
+    assert l1 != base_loss and l2 != l1 and abs(l1 - base_loss) < 0.2 * base_loss
+    # hold the mask: every forward below runs at device seed 5
+    ts._drop_seed.fill_(4)
+    loss0 = ts.forward().item()
+    ts.backward()
+    st = ts.store
+    g = {i: (st.grad_view(f"lora.{i}.A").clone(), st.grad_view(f"lora.{i}.B").clone()) for i in range(n_ad)}
+    gnorm2 = sum(a.double().pow(2).sum().item() + b.double().pow(2).sum().item() for a, b in g.values())
+    A0 = [ad.A.clone() for ad in lora.adapters]
+    B0 = [ad.B.clone() for ad in lora.adapters]
+    deltas = []
+    for target in (0.02, 0.04):
+        eps = target * loss0 / gnorm2
+        for i, ad in enumerate(lora.adapters):
+            ad.A.copy_((A0[i].float() - eps * g[i][0].view(ad.A.shape)).to(torch.bfloat16))
+            ad.B.copy_((B0[i].float() - eps * g[i][1].view(ad.B.shape)).to(torch.bfloat16))
+        ops.run_all(ts._adapter_ops)
+        ts._drop_seed.fill_(4)
+        d = ts.forward().item() - loss0
+        deltas.append((target * loss0, d))
+        print(f"lora dropout directional derivative: predicted {-target * loss0:.4f}, measured {d:.4f}")
+    for pred, d in deltas:
+        assert abs(d + pred) <= 0.25 * pred + 2e-3, (pred, d)
+    assert deltas[1][1] < deltas[0][1] < 0
+    # (iv) one adapted linear in isolation (o_proj of the last layer), sharp: with a random dy the plan's dx and dA must match the
+    # masked formulas — and must NOT match the un-masked ones (the whole-model derivative above is dominated by the base path)
+    from oracle.synth import dropout_keep
+    for i, ad in enumerate(lora.adapters):
+        ad.A.copy_(A0[i]); ad.B.copy_(B0[i])
+    ops.run_all(ts._adapter_ops)
+    ts._drop_seed.fill_(4)
+    ts.forward()                                                   # seed 5; fills ao / t of every adapted linear
+    l = dims.llm_layers - 1
+    packed = w.layers[l].o_w
+    ad = lora.get(packed)
+    Tn, D = ts.T, dims.llm_dim
+    g_ = torch.Generator().manual_seed(11)
+    dy = (torch.randn(Tn, D, generator=g_) * 0.5).to(torch.bfloat16)
+    ts.dxb[:, :D].copy_(dy.to(dev))
+    ops.run_all(ts._lin_bwd(ts.dxb, ts.ao[l], packed, ts.dao))
+    x = ts.ao[l][:, :D].float().cpu()
+    Wm = ops.unpack_weight(packed).float().cpu()                   # [D, D]
+    A, Bm = ad.A.float().cpu()[:, :D], ad.B.float().cpu()          # [R, D], [D, R]
+    keep = torch.from_numpy(dropout_keep(5, ad.index, Tn, D, 0.25))
+    mt = keep.float() / 0.75
+    dt = (dy.float() @ (lora.scaling * Bm)).to(torch.bfloat16).float()          # [T, R]
+    dx_masked = dy.float() @ Wm + (dt @ A) * mt
+    dx_plain = dy.float() @ Wm + dt @ A
+    got_dx = ts.dao[:, :D].float().cpu()
+    e_masked = (got_dx - dx_masked).norm() / dx_masked.norm()
+    e_plain = (got_dx - dx_plain).norm() / dx_plain.norm()
+    dA_masked, dA_plain = dt.t() @ (x * mt), dt.t() @ x
+    got_dA = st.grad_view(f"lora.{ad.index}.A").view(ad.A.shape)[:, :D].float().cpu()
+    c_masked, c_plain = cos(got_dA, dA_masked), cos(got_dA, dA_plain)
+    print(f"o_proj in isolation: dx rel. error vs masked formula {e_masked:.2e} (vs un-masked {e_plain:.2e}); dA cosine {c_masked:.5f} (un-masked {c_plain:.5f})")
+    assert e_masked < 1e-2 and e_plain > 3 * e_masked
+    assert c_masked > 0.9995 and c_plain < 0.999

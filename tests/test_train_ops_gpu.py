@@ -354,3 +354,34 @@ def test_training_epilogues_equal_the_two_kernel_forms(dev, M, N, K):
     T.gelu_backward(saved_t, d_act, dt_a)
     ops.gemm(x, wp, dt_b, ops.EPI_GELU_BWD, res=saved_t)
     assert torch.equal(bits(dt_a), bits(dt_b)) and dt_b.float().abs().max() > 0
+
+
+@pytest.mark.parametrize("rows,cols,p", [(300, 256, 0.1), (77, 1152, 0.5), (64, 64, 0.0)])
+def test_lora_dropout_kernels(dev, rows, cols, p):
+    """bl_dropout_bf16 / bl_dropout_grad_fix_bf16 against the host restatement of the counter-based mask
+    (oracle/synth.py::dropout_keep): same keep pattern, nn.Dropout's 1/(1-p) scaling, and the input-gradient correction
+    dy·W + u → dy·W + mask/(1-p) ⊙ u; a different device seed or salt gives a different mask."""
+    from bridgelang_amd import train_ops as T
+    from oracle.synth import dropout_keep
+    x, u, dx0 = rand_bf16((rows, cols), 1), rand_bf16((rows, cols), 2), rand_bf16((rows, cols), 3)
+    seed = torch.tensor([41], dtype=torch.int32, device=dev)
+    out = torch.full((rows, cols), 9.0, dtype=torch.bfloat16, device=dev)
+    T.dropout(dv(x, dev), out, p, seed, 7)
+    keep = torch.from_numpy(dropout_keep(41, 7, rows, cols, p))
+    inv = torch.tensor(1.0 / (1.0 - p), dtype=torch.float32)
+    want = torch.where(keep, P.rb(x * inv), torch.zeros(()))
+    assert torch.equal(out.cpu().float(), want)
+    if p > 0:
+        assert abs(keep.float().mean().item() - (1 - p)) < 0.02
+        other = torch.empty_like(out)
+        T.dropout(dv(x, dev), other, p, seed, 8)
+        assert not torch.equal(other, out)
+        seed2 = torch.tensor([42], dtype=torch.int32, device=dev)
+        T.dropout(dv(x, dev), other, p, seed2, 7)
+        assert not torch.equal(other, out)
+    else:
+        assert bool(keep.all())
+    DX = dv(dx0, dev)
+    T.dropout_grad_fix(dv(u, dev), DX, p, seed, 7)
+    want_dx = P.rb(dx0 + torch.where(keep, P.rb(u * (inv - 1.0)), -u))
+    assert torch.equal(DX.cpu().float(), want_dx)
