@@ -138,3 +138,38 @@ def test_sharded_adamw_gloo_world2_fp32(tmp_path):
 
 def test_sharded_adamw_gloo_world2_bf16_reduce(tmp_path):
     _run(tmp_path, "bf16", 29542)
+
+
+def test_full_shard_covers_every_fsdp_unit_of_the_reference():
+    """fsdp-full-shard's bookkeeping on the CPU (no kernels): with `shard_params` the ParamStore of a full fine-tune shards the
+    parameters AND gradients of every FSDP unit the reference wraps — each ViT block and patch embedding, the projector, every
+    decoder layer, and the root's token embeddings / lm_head (prismatic.py:285-306, dinosiglip_vit.py:136-140, fsdp.py:160-168);
+    the sharded buckets are one contiguous range of the flat space, the rank keeps 1/world of them, and only the small plain
+    tensors (norm scales, biases, position / class tokens) stay replicated. Vision frozen (vla-train): the vision units drop out,
+    the rest is unchanged."""
+    from bridgelang_amd.training.step import ParamStore, param_sharded_key, pool_of
+    from bridgelang_amd.weights import allocate, tiny_dims
+    dims = tiny_dims()
+    w = allocate(dims, "cpu")
+    for world in (1, 2):
+        for stage in ("vla-full-train", "vla-train"):
+            st = ParamStore(w, stage, world, world - 1, shard_params=True, defer_grads=True)
+            keys = [b.key for b in st.layout.buckets]
+            sharded = [k for k in keys if k in st.sharded_keys]
+            assert all(param_sharded_key(k) for k in sharded) and not any(param_sharded_key(k) for k in keys if k not in st.sharded_keys)
+            assert {"projector", "llm.lm_head", "llm.embed"} <= set(sharded)
+            assert sum(k.startswith("llm.layer") for k in sharded) == dims.llm_layers
+            n_vis = sum(k.startswith("vision.") for k in sharded)
+            assert n_vis == (dims.dino.n_run + dims.siglip.n_run + 2 if stage == "vla-full-train" else 0)
+            assert {pool_of(k) for k in sharded} == ({"layers", "head", "vision"} if n_vis else {"layers", "head"})
+            lo, hi = st._cut                                      # contiguous: [first sharded bucket, last sharded bucket)
+            assert sum(b.numel for b in st.layout.buckets if b.key in st.sharded_keys) == hi - lo
+            rest = [k for k in keys if k not in st.sharded_keys]
+            assert set(rest) <= {"plain.decay", "plain.nodecay"}
+            replicated = sum(b.numel for b in st.layout.buckets if b.key not in st.sharded_keys)
+            assert replicated <= 0.02 * st.layout.total
+            assert st.own.numel() * world <= (hi - lo) + 8 and st.stage_bf16.numel() <= replicated + 8
+            # two gradient-slot parities per pool, alternating along each pool's unit order
+            for pool in {pool_of(k) for k in sharded}:
+                par = [st.grad_slot_of[k][1] for k in keys if k in st.sharded_keys and pool_of(k) == pool and pool != "layers"]
+                assert par == [i % 2 for i in range(len(par))]
