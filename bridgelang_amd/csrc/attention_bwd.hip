@@ -160,6 +160,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(BwdArgs p, int s_pad) 
     f32x4_t acc[DT];
 #pragma unroll
     for (int i = 0; i < DT; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1   // one scheduled body: unrolled, hipcc reuses ONE fragment buffer from the second step on (read, wait, MFMA, read, …)
     for (int s2 = 0; s2 * 32 < kv_hi; ++s2) {
       float e[8];
       const uint32_t vis8 = ((s2 < 4 ? mb0 : (s2 < 8 ? mb1 : mb2)) >> ((s2 & 3) * 8)) & 0xffu;   // bits half·4 + rr of this step
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(BwdArgs p, int s_pad)
       ln[half] = *(const f32x4_t*)(lse + (2 * (q_lo >> 5) + half) * 16 + lg * 4);
       dn[half] = *(const f32x4_t*)(delta + (2 * (q_lo >> 5) + half) * 16 + lg * 4);
     }
+#pragma unroll 1
     for (int s2 = q_lo >> 5; s2 * 32 < p.Sq; ++s2) {
       float pe[8], de[8];
       f32x4_t lc[2] = {ln[0], ln[1]}, dc[2] = {dn[0], dn[1]};
@@ -405,6 +407,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_chunk_kernel(BwdArgs p) {
                         min(KC, p.Skv - key0), tid);
     if (tid < KC) m_lds[tid] = (key0 + tid < p.Skv && (mrow == nullptr || mrow[key0 + tid] != 0)) ? 1 : 0;
     __syncthreads();
+#pragma unroll 1
     for (int s2 = 0; s2 < KC / 32 && key0 + s2 * 32 < kv_hi; ++s2) {
       float e[8];
 #pragma unroll
@@ -501,6 +504,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_chunk_kernel(BwdArgs p) {
     stage_two<HD, ROWB>(q_lds, g_lds, qbase + (long)qc0 * p.q_rs, p.q_rs, gbase + (long)qc0 * p.o_rs, p.o_rs, KC,
                         min(KC, p.Sq - qc0), tid);
     __syncthreads();
+#pragma unroll 1
     for (int s2 = max(s2_wave, qc0 >> 5); s2 * 32 < min(p.Sq, qc0 + KC); ++s2) {
       float pe[8], de[8];
       const int lrow = s2 * 32 - qc0;                                // row of this step inside the staged chunk
