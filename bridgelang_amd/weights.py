@@ -4,7 +4,9 @@ On-disk naming follows the reference's HF layout (vla-scripts/extern/convert_ope
 `vision_backbone.featurizer.*` (DINOv2), `vision_backbone.fused_featurizer.*` (SigLIP), `projector.fc{1,2,3}.*`,
 `language_model.*`, LayerScale as `.scale_factor` (modeling_prismatic.py:52-59).
 
-Device layout (one bf16 arena, 256-byte aligned sub-tensors; 15 GB at 7B — a fraction of the 288 GB HBM3E):
+Device layout (bf16 arenas of 256-byte aligned sub-tensors, 15 GB at 7B — a fraction of the 288 GB HBM3E; four allocations: the
+decoder layers' GEMM weights, the vision units', the head units' — projector, token embeddings, lm_head — each releasable under
+parameter-sharded training, and the small plain tensors):
   * K dimensions padded to multiples of 64 (patch-embed 588→640, SigLIP MLP 4304→4352) so GEMM tiles never straddle a
     row end; the pad is zero and never leaves HBM/LDS.
   * Llama q/k/v stacked into one [3D, D] matrix; gate/up interleaved row-wise (2j = gate_j, 2j+1 = up_j) so the SwiGLU
