@@ -542,6 +542,153 @@ __global__ __launch_bounds__(256, 2) void gemm_mid_kernel(GemmArgs p) {
 }
 
 // ======================================================================================================================
+// "rows-stream" kernel: the skinny order at M ≤ 96 rows (the merged decode iteration) as a WEIGHT-STREAMING kernel for the
+// wide layers. Every wave owns one 16-column weight tile and walks the workgroup's K range; weight fragments go
+// HBM → VGPR with non-temporal 16-byte loads straight out of the fragment-major packing (never through LDS) into a ring
+// of NWB register buffers of GS k-steps: NWB − 1 groups (12 KiB per wave) are in flight while one is consumed. The ≤ 96
+// activation rows of a GS-k-step chunk are staged ONCE per workgroup by LDS-DMA (the mid kernel's swizzled 128-byte rows,
+// a ring of NWB chunks) and read by every wave as 6 B-fragments per weight fragment: 0.75 – 1.0 staged bytes per weight
+// byte instead of the mid kernel's 3 — what a CU can pull through its vector-memory path is capped (≈ 64 KiB of requests
+// outstanding: ≈ 57 GB/s per CU out of HBM, tools/micro/hbm_stream.hip), so staged activation bytes cost weight bytes.
+// One raw barrier per chunk; counted vmcnt: every wave issues exactly OPS = XP + GS vector-memory operations per chunk
+// on every path (surplus chunks re-read the last one), so vmcnt(2·OPS) always leaves exactly the two younger chunks in
+// flight and hipcc's own counting for the weight registers comes out the same. The refill of the slot freed by the
+// previous chunk is issued a quarter at a time BEHIND each k-step's MFMAs: a load that stalls at issue because the CU's
+// request queue is full then stalls under MFMAs that are already in the pipe (−5 % against issuing it in one block).
+// Slices, the binary-counter fold and the grid.y split are gemm_mid_kernel<SK>'s: results are bit-identical to it and to
+// gemm_skinny_kernel. ALIGNED: fold_ks is a multiple of GS (K = 4096 / 5120: slices end on chunk boundaries) — the
+// slice-boundary test runs once per chunk.
+// ======================================================================================================================
+template <int EPI, int NWV, int SK, bool ALIGNED>
+__global__ __launch_bounds__(NWV * 64) void gemm_rows_stream_kernel(GemmArgs p, int n_tiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int MR = 6, GS = 4, NWB = 4;
+  constexpr int KT_BYTES = MR * 16 * ROW_BYTES, XBUF = 2 * KT_BYTES;   // one K-tile (2 k-steps) of all rows; one chunk
+  constexpr int XP = 24 / NWV, OPS = XP + GS;
+  static_assert(24 % NWV == 0 && XP <= GS, "the chunk's 24 LDS-DMA pieces are dealt evenly to the waves, one per k-step");
+  constexpr int LV = SK >= 8 ? 3 : SK >= 4 ? 2 : SK >= 2 ? 1 : 0;
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // NWB × XBUF
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int tile_raw = (int)blockIdx.x * NWV + wave;
+  const bool live = tile_raw < n_tiles;
+  const int tile = live ? tile_raw : n_tiles - 1;        // a surplus wave streams the last tile again and stores nothing
+  const int kt32 = p.K >> 5;
+  const int ks0 = (int)blockIdx.y * SK * p.fold_ks, nks = SK * p.fold_ks;   // this workgroup's k-steps [ks0, ks0 + nks)
+  const int NC = (nks + GS - 1) / GS;
+
+  const unsigned a_bytes = (unsigned)min((long)p.M * p.lda * 2, 0xffffffffL);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
+  // activation pieces (8 rows × 128 B): piece q = j·NWV + wave → K-tile q / 12 of the chunk, row block q % 12
+  const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
+  unsigned voffA[XP];
+  int ldsA[XP];
+#pragma unroll
+  for (int j = 0; j < XP; ++j) {
+    const int q = j * NWV + wave, kt = q / 12, rb = q - kt * 12;
+    voffA[j] = (unsigned)(((long)(rb * 8 + prow) * p.lda) * 2 + kt * 128 + pchunk * 16);
+    ldsA[j] = kt * KT_BYTES + rb * 1024;
+  }
+  const u32x4_t* wbase = (const u32x4_t*)p.W + ((long)tile * kt32 + ks0) * 64 + lane;
+  u32x4_t wbuf[NWB][GS];
+
+  // part J (of GS) of chunk C into ring slot SLOT: LDS-DMA piece J (if the wave has one) and weight fragment J. Chunk
+  // and k-step indices are clamped, so every call issues the same operations whatever C is.
+#define BL_RS_ISSUE_PART(SLOT, C, J)                                                                          \
+  do {                                                                                                        \
+    const int cc__ = min((C), NC - 1);                                                                        \
+    if ((J) < XP) BL_GLDS(rsA, smem + (SLOT) * XBUF + ldsA[(J) < XP ? (J) : 0], voffA[(J) < XP ? (J) : 0], (ks0 + cc__ * GS) * 64); \
+    wbuf[SLOT][J] = __builtin_nontemporal_load(wbase + (long)min(cc__ * GS + (J), nks - 1) * 64);             \
+  } while (0)
+#define BL_RS_READX(DST, XB, S)                                                                               \
+  do {                                                                                                        \
+    const char* xs__ = (XB) + ((S) >> 1) * KT_BYTES + offA + ((c0 ^ (((S) & 1) * 4)) << 4);                    \
+    _Pragma("unroll") for (int j = 0; j < MR; ++j) DST[j] = *(const bf16x8_t*)(xs__ + j * 16 * ROW_BYTES);    \
+  } while (0)
+#define BL_RS_FOLD_LEVEL(L)                                                                \
+  if constexpr (LV > L) {                                                                   \
+    if (!parked) {                                                                          \
+      if (!((sl >> L) & 1)) {                                                               \
+        _Pragma("unroll") for (int j = 0; j < MR; ++j) hold[L][j] = acc[j];                 \
+        parked = true;                                                                      \
+      } else {                                                                              \
+        _Pragma("unroll") for (int j = 0; j < MR; ++j) acc[j] = hold[L][j] + acc[j];        \
+      }                                                                                     \
+    }                                                                                       \
+  }
+  // one chunk: counted wait, barrier (every wave's pieces of chunk C have landed; every wave is done with chunk C − 1, whose
+  // ring slot the refill below overwrites), then GS × (next k-step's fragments LDS → VGPR, 6 MFMAs, a quarter of the refill)
+#define BL_RS_CHUNK(SLOT, C)                                                                                  \
+  {                                                                                                           \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");                                            \
+    __builtin_amdgcn_s_barrier();                                                                             \
+    const char* xb = smem + (SLOT) * XBUF;                                                                    \
+    bf16x8_t xf[2][MR];                                                                                       \
+    BL_RS_READX(xf[0], xb, 0);                                                                                \
+    _Pragma("unroll") for (int s2 = 0; s2 < GS; ++s2) {                                                       \
+      if (s2 + 1 < GS) BL_RS_READX(xf[(s2 + 1) & 1], xb, s2 + 1);                                             \
+      __builtin_amdgcn_sched_barrier(0);   /* next k-step's fragments are in flight under this one's MFMAs */ \
+      const int kidx = (C) * GS + s2;                                                                         \
+      if (kidx < nks) {                                                                                       \
+        const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wbuf[SLOT][s2]);                                     \
+        _Pragma("unroll") for (int j = 0; j < MR; ++j)                                                        \
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[s2 & 1][j], acc[j], 0, 0, 0);               \
+        if (SK > 1 && (!ALIGNED || s2 == GS - 1) && kidx + 1 == fold_next) {                                  \
+          bool parked = false;                                                                                \
+          /* opaque to the optimiser, as in gemm_mid_kernel: no speculated VALU read of the accumulators */    \
+          _Pragma("unroll") for (int j = 0; j < MR; ++j) asm volatile("" : "+v"(acc[j]));                     \
+          BL_RS_FOLD_LEVEL(0) BL_RS_FOLD_LEVEL(1) BL_RS_FOLD_LEVEL(2)                                         \
+          if (parked) {                                                                                       \
+            _Pragma("unroll") for (int j = 0; j < MR; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};            \
+          }                                                                                                   \
+          fold_next += p.fold_ks;                                                                             \
+          ++sl;                                                                                               \
+        }                                                                                                     \
+      }                                                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      BL_RS_ISSUE_PART(((SLOT) + NWB - 1) % NWB, (C) + NWB - 1, s2);                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+    }                                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+  }
+
+  const int c0 = lg ^ (lane & 7);
+  const int offA = l15 * ROW_BYTES;
+  f32x4_t acc[MR], hold[LV ? LV : 1][MR];
+#pragma unroll
+  for (int j = 0; j < MR; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  int fold_next = p.fold_ks, sl = 0;
+
+  // prologue: chunks 0 … NWB-2 in flight, chunk by chunk (the counted waits rely on whole chunks being issued in order)
+#pragma unroll
+  for (int c = 0; c < NWB - 1; ++c) {
+#pragma unroll
+    for (int j = 0; j < GS; ++j) BL_RS_ISSUE_PART(c, c, j);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int cb = 0; cb < NC; cb += NWB) {   // whole rounds of NWB chunks; chunks past NC only skip their MFMAs
+    BL_RS_CHUNK(0, cb)
+    BL_RS_CHUNK(1, cb + 1)
+    BL_RS_CHUNK(2, cb + 2)
+    BL_RS_CHUNK(3, cb + 3)
+  }
+#undef BL_RS_CHUNK
+#undef BL_RS_FOLD_LEVEL
+#undef BL_RS_READX
+#undef BL_RS_ISSUE_PART
+  if (!live) return;
+  float* slab = p.slab + (long)blockIdx.y * p.M * p.N;
+#pragma unroll
+  for (int j = 0; j < MR; ++j) {
+    const int m = j * 16 + l15, n = tile * 16 + lg * 4;
+    if (gridDim.y == 1) epilogue_store4<EPI>(p, m, n, acc[j]);
+    else if (m < p.M) *(f32x4_t*)(slab + (long)m * p.N + n) = acc[j];
+  }
+#endif
+}
+
+// ======================================================================================================================
 // "mid2" kernel: 160 rows × 32 columns per workgroup, 4 waves as 2 (m) × 2 (n), 3-stage ring — the narrow layers
 // (N = 4096 o / down, ViT proj / fc2) at 128 < M ≤ 320. The mid kernel's 16-column slabs re-stage ALL rows of A per
 // workgroup (42 KB per K-step for 0.66 MFLOP), and the CU's global→LDS path (one 1-KiB piece per ≈ 20 cycles) is what
@@ -1440,7 +1587,22 @@ bool mid_attr() {
                              hipFuncAttributeMaxDynamicSharedMemorySize, mid_lds_bytes<MB, NB>()) == hipSuccess;
 }
 
-// bl_gemm_skinny_rows_bf16: M <= 128 rows through gemm_mid_kernel in the skinny kernel's summation order
+constexpr int RS_LDS_BYTES = 4 * 2 * 6 * 16 * ROW_BYTES;   // gemm_rows_stream_kernel: NWB chunks of 96 rows × 2 K-tiles
+template <int EPI, int NWV, int SK>
+int launch_rs(const GemmArgs& p, hipStream_t s, int n_tiles) {
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_stream_kernel<EPI, NWV, SK, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES) != hipSuccess) return BL_E_LAUNCH;
+    done = true;
+  }
+  hipLaunchKernelGGL((gemm_rows_stream_kernel<EPI, NWV, SK, true>), dim3((n_tiles + NWV - 1) / NWV, 8 / SK), dim3(NWV * 64),
+                     RS_LDS_BYTES, s, p, n_tiles);
+  return BL_OK;
+}
+
+// bl_gemm_skinny_rows_bf16: M <= 128 rows in the skinny kernel's summation order — gemm_rows_stream_kernel for the wide
+// layers at M <= 96 (qkv, gate/up, lm_head), gemm_mid_kernel<SK> otherwise
 template <int EPI>
 int launch_rows_sk(const GemmArgs& a, hipStream_t s) {
   static bool done = false;
@@ -1450,6 +1612,32 @@ int launch_rows_sk(const GemmArgs& a, hipStream_t s) {
   }
   GemmArgs p = a;
   p.fold_ks = p.K / 256;                       // 8 slices of K/8 columns = K/256 MFMA k-steps each
+  // Rows-stream form: slices that end on its 4-k-step chunks (K a multiple of 1024), more than 256 weight tiles (the narrow
+  // layers' two launches — K split + reduce — are launch-bound and the mid kernel's are shorter: o 16.7 vs 19.5 µs, down
+  // 28.3 vs 33.5). 7B at 96 rows, same box: gate/up 53.5 → 40.2 µs (6 waves × 230 workgroups), qkv 38.1 → 32.7 (8 waves ×
+  // 96 column groups × 2 K-halves + the tree's last level in the reduce kernel). BL_ROWS_STREAM=0 switches it off (A/B).
+  const int n_tiles = p.N / 16;
+  const char* e_on = getenv("BL_ROWS_STREAM");
+  if (p.M <= 96 && p.fold_ks % 4 == 0 && n_tiles > 256 && (e_on ? atoi(e_on) : 1)) {
+    const bool can_split = p.slab && p.slab_bytes >= 2L * p.M * p.N * 4;
+    int rc;
+    if ((n_tiles + 7) / 8 >= 200) {                       // one round of 8-wave workgroups fills the chip (lm_head)
+      p.splitk = 1;
+      rc = launch_rs<EPI, 8, 8>(p, s, n_tiles);
+    } else if ((n_tiles + 5) / 6 >= 200 || !can_split) {  // 6-wave workgroups do (gate/up: 230)
+      p.splitk = 1;
+      rc = launch_rs<EPI, 6, 8>(p, s, n_tiles);
+    } else {                                              // two K-halves of 4 slices each + the last tree level
+      p.splitk = 2;
+      rc = launch_rs<BL_EPI_NONE, 8, 4>(p, s, n_tiles);
+      const long work = (long)p.M * (p.N / 4);
+      if (rc == BL_OK)
+        hipLaunchKernelGGL((gemm_rows_tree_reduce_kernel<EPI>), dim3((int)min((work + 255) / 256, 2048L)), dim3(256), 0, s, p);
+    }
+    if (rc != BL_OK) return rc;
+    BL_CHECK_LAUNCH();
+    return BL_OK;
+  }
   const int slabs64 = (p.N + 63) / 64;
   // 64-column slabs, every weight byte once, all rows of A staged once per workgroup. Where that leaves most CUs without
   // a workgroup (N = 4096: 64 slabs) and the caller gave a workspace, grid.y = 4 workgroups take two K-slices each and

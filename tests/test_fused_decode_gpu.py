@@ -70,7 +70,11 @@ def test_attention_decode_rope(dev, pos):
 
 
 @pytest.mark.parametrize("M,N,K", [(96, 4096, 4096), (96, 1024, 11008), (17, 512, 512), (128, 3072, 1536), (40, 2048, 1024),
-                                   (112, 640, 5120), (96, 256, 13824), (33, 22016, 512)])
+                                   (112, 640, 5120), (96, 256, 13824), (33, 22016, 512),
+                                   # the wide layers' weight-streaming form (gemm_rows_stream_kernel): 6-wave workgroups walking
+                                   # all of K (gate/up), two K-halves + tree reduce (qkv), 8-wave workgroups (lm_head width),
+                                   # ragged row counts, a surplus wave in the last workgroup (6176 / 16 = 386 tiles)
+                                   (96, 22016, 4096), (70, 12288, 4096), (96, 32064, 1024), (16, 6176, 5120), (1, 8192, 1024)])
 def test_skinny_rows_bit_identical_to_skinny(dev, M, N, K):
     """bl_gemm_skinny_rows_bf16 (up to 128 stacked rows, the merged decode iteration) must give every row EXACTLY what
     bl_gemm_skinny_bf16 gives that row in a batch of <= 16 — same 8-way K partition, per-slice k order and combine order
