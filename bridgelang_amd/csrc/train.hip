@@ -9,6 +9,8 @@
 // treats a dtype cast.
 #include "bl_common.h"
 #include <math.h>
+#include <algorithm>
+#include <stdlib.h>
 
 namespace bl_train_impl {
 
@@ -75,12 +77,22 @@ __global__ __launch_bounds__(256) void ce_backward_kernel(const float* logits, l
 // 1.7 TB/s (RMSNorm, dim 4 K). x and dy stay PACKED in registers (4 VGPRs per 8 values) and are unpacked in each pass.
 template <int NCH> constexpr int norm_bwd_rpw() { return NCH <= 3 ? 4 : NCH <= 4 ? 2 : 1; }
 
-template <int NCH, bool LN>
-__global__ __launch_bounds__(256) void norm_bwd_kernel(const uint16_t* x, long ldx, const uint16_t* w,
+// DRL (one row per wave, dim > 2 K: the decoder's RMSNorm, which always adds the residual-stream gradient): the row of
+// dres travels HBM → LDS by LDS-DMA (NCH wave-instructions of 1 KiB, lane-linear = the register layout) while the three
+// reduction passes run, and is read with ds_read_b128 in the output pass. Loaded inside that pass, chunk by chunk behind
+// the arithmetic that consumes it, it cost 42 of the kernel's 111 µs at 7B (69 µs without dres); as a fourth register set
+// it would halve the occupancy (248 VGPRs already). Same arithmetic: results are bit-identical.
+// NCH <= 2 (DINOv2's LayerNorm, dim 1024): three workgroups per CU — 32 x 261 rows in blocks of 16 are 522 blocks, which
+// two per CU (181 VGPRs left alone) run as one round of 512 and a second one of 10.
+template <int NCH, bool LN, bool DRL = false>
+__global__ __launch_bounds__(256, NCH <= 2 ? 3 : 1) void norm_bwd_kernel(const uint16_t* x, long ldx, const uint16_t* w,
                                                        const uint16_t* dy, long lddy, const uint16_t* dres,
                                                        long lddres, uint16_t* dx, long lddx, float* dw_partial,
                                                        int rows, int dim, float eps, int rows_per_block) {
+#if defined(__HIP_DEVICE_COMPILE__)   // __amdgpu_buffer_rsrc_t does not exist in the host pass
   constexpr int RPW = norm_bwd_rpw<NCH>();
+  static_assert(!DRL || RPW == 1, "the LDS path of dres is written for one row per wave");
+  __shared__ __attribute__((aligned(16))) char drl[DRL ? 4 * NCH * 1024 : 16];   // [wave][NCH KiB]
   // the packed registers are re-read through an empty asm before each pass: otherwise hipcc keeps every unpacked float of
   // every row alive across the passes (256 VGPRs + 250 AGPRs, one wave per SIMD)
 #define BL_FRESH(Q) asm volatile("" : "+v"(Q))
@@ -93,8 +105,23 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const uint16_t* x, long l
 #pragma unroll
     for (int i = 0; i < 8; ++i) { dwacc[c][i] = 0.f; if (LN) dbacc[c][i] = 0.f; }
   const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  // the norm weight, once per block, in LDS: read from global inside the two passes that use it (one 16-byte load per
+  // chunk, each behind the arithmetic of the chunk before — the kernel has no registers to batch them) every row paid
+  // 2 · NCH dependent L2 round trips
+  __shared__ __attribute__((aligned(16))) u32x4_t wl[NCH * 64];
+  for (int ch = threadIdx.x; ch < NCH * 64; ch += 256) wl[ch] = ch < nchunk ? *(const u32x4_t*)(w + ch * 8) : (u32x4_t){0u, 0u, 0u, 0u};
+  __syncthreads();
+  __amdgpu_buffer_rsrc_t rsr;
+  char* mydrl = drl + (DRL ? wave * NCH * 1024 : 0);
+  if constexpr (DRL) rsr = __builtin_amdgcn_make_buffer_rsrc((void*)dres, 0, (unsigned)((long)r1 * lddres * 2), 0x00020000);
   for (int rr = r0 + wave * RPW; rr < r1; rr += 4 * RPW) {
     u32x4_t qx[RPW][NCH], qd[RPW][NCH];
+    if constexpr (DRL) {      // dim == NCH · 512 (launcher): every chunk is whole. The previous row's ds_reads are complete.
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsr, LDS_PTR(mydrl + c * 1024), 16, lane * 16,
+                                                 (unsigned)((long)rr * lddres * 2) + c * 1024, 0, 0);
+    }
 #pragma unroll
     for (int u = 0; u < RPW; ++u)
 #pragma unroll
@@ -147,7 +174,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const uint16_t* x, long l
       for (int c = 0; c < NCH; ++c) {
         const int ch = c * 64 + lane;
         float wv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, xv[8], dv[8];
-        if (ch < nchunk) unpack8(*(const u32x4_t*)(w + ch * 8), wv);
+        if (ch < nchunk) unpack8(wl[ch], wv);
         BL_FRESH(qx[u][c]); BL_FRESH(qd[u][c]);
         unpack8(qx[u][c], xv); unpack8(qd[u][c], dv);
 #pragma unroll
@@ -161,6 +188,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const uint16_t* x, long l
       dot[u] = wave_sum(d) * inv_dim;
       gsum[u] = LN ? wave_sum(g1) * inv_dim : 0.f;
     }
+    if constexpr (DRL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dres row is in LDS (issued three passes ago)
 #pragma unroll
     for (int u = 0; u < RPW; ++u) {
       const int row = rr + u;
@@ -169,10 +197,11 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const uint16_t* x, long l
         const int ch = c * 64 + lane;
         if (ch >= nchunk || row >= r1) continue;
         float o[8], dr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wv[8], xv[8], dv[8];
-        unpack8(*(const u32x4_t*)(w + ch * 8), wv);
+        unpack8(wl[ch], wv);
         BL_FRESH(qx[u][c]); BL_FRESH(qd[u][c]);
         unpack8(qx[u][c], xv); unpack8(qd[u][c], dv);
-        if (dres) unpack8(*(const u32x4_t*)(dres + (long)row * lddres + ch * 8), dr);
+        if constexpr (DRL) unpack8(*(const u32x4_t*)(mydrl + c * 1024 + lane * 16), dr);
+        else if (dres) unpack8(*(const u32x4_t*)(dres + (long)row * lddres + ch * 8), dr);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float xh = (LN ? xv[i] - mu[u] : xv[i]) * rstd[u];
@@ -183,6 +212,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const uint16_t* x, long l
         *(u32x4_t*)(dx + (long)row * lddx + ch * 8) = pack8(o);
       }
     }
+    if constexpr (DRL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // dres row consumed before the next one lands on it
   }
   // per-block partials: the 4 waves of the block own disjoint rows → sum them through LDS, lane-major
   __shared__ float sh[4][64 * 8];
@@ -206,10 +236,14 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const uint16_t* x, long l
     }
   }
 #undef BL_FRESH
+#endif
 }
 
 // out[j] = Σ_b partial[b][j]   (fixed order → deterministic). Block = 64 columns × 4 row groups.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* partial, int nblocks, int dim, float* out) {
+// grid.y = 1: a second set of partials (LayerNorm's db, stored behind the dw partials) goes to out2 in the same launch.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* partial, int nblocks, int dim, float* out,
+                                                              float* out2 = nullptr) {
+  if (blockIdx.y) { partial += (long)nblocks * dim; out = out2; }
   __shared__ float sh[4][64];
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + c;
@@ -855,17 +889,28 @@ static int norm_backward(const bl_bf16* x, int64_t ldx, const bl_bf16* w, const 
     rpb *= 2;
     if (rpb > 4096) return BL_E_SHAPE;
   }
-  const int nblk = (rows + rpb - 1) / rpb;
   const int nch = (dim / 8 + 63) / 64;
+  // one row per wave (nch >= 5): two workgroups per CU = 512 resident blocks. 9472 rows in blocks of 16 are 592 blocks = one
+  // full round and a second one of 80; blocks of 20 rows (five per wave) are 474 = one round (92 -> 80 us at 7B).
+  if (nch >= 5 && (rows + rpb - 1) / rpb > 512) rpb = std::max(rpb, ((rows + 511) / 512 + 3) / 4 * 4);
+  const int nblk = (rows + rpb - 1) / rpb;
   hipStream_t s = (hipStream_t)stream;
 #define BL_CASE(N) case N: hipLaunchKernelGGL((norm_bwd_kernel<N, LN>), dim3(nblk), dim3(256), 0, s, x, (long)ldx, w, dy, \
     (long)lddy, dres, (long)lddres, dx, (long)lddx, partial_ws, rows, dim, eps, rpb); break;
-  switch (nch) { BL_CASE(1) BL_CASE(2) BL_CASE(3) BL_CASE(4) BL_CASE(5) BL_CASE(6) BL_CASE(7) BL_CASE(8) BL_CASE(9) BL_CASE(10)
-    default: return BL_E_SHAPE; }
+#define BL_CASE_DRL(N) case N: hipLaunchKernelGGL((norm_bwd_kernel<N, LN, true>), dim3(nblk), dim3(256), 0, s, x, (long)ldx, w, dy, \
+    (long)lddy, dres, (long)lddres, dx, (long)lddx, partial_ws, rows, dim, eps, rpb); break;
+  // dres through LDS: one row per wave (nch >= 5), whole 512-column chunks, 32-bit buffer offsets. BL_NORM_BWD_DRL=0: A/B.
+  static const int drl_on = getenv("BL_NORM_BWD_DRL") ? atoi(getenv("BL_NORM_BWD_DRL")) : 1;
+  const bool drl = drl_on && !LN && dres && nch >= 5 && dim == nch * 512 && (long)rows * lddres * 2 < (1L << 32) && bl_aligned16(dres);
+  if (drl) {
+    switch (nch) { BL_CASE_DRL(5) BL_CASE_DRL(6) BL_CASE_DRL(7) BL_CASE_DRL(8) BL_CASE_DRL(9) BL_CASE_DRL(10) default: return BL_E_SHAPE; }
+  } else {
+    switch (nch) { BL_CASE(1) BL_CASE(2) BL_CASE(3) BL_CASE(4) BL_CASE(5) BL_CASE(6) BL_CASE(7) BL_CASE(8) BL_CASE(9) BL_CASE(10)
+      default: return BL_E_SHAPE; }
+  }
 #undef BL_CASE
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((dim + 63) / 64), dim3(256), 0, s, partial_ws, nblk, dim, dw);
-  if (LN)
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((dim + 63) / 64), dim3(256), 0, s, partial_ws + (long)nblk * dim, nblk, dim, db);
+#undef BL_CASE_DRL
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((dim + 63) / 64, LN ? 2 : 1), dim3(256), 0, s, partial_ws, nblk, dim, dw, db);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }
@@ -906,7 +951,7 @@ extern "C" int bl_layerscale_backward_bf16(const bl_bf16* dy, int64_t lddy, cons
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(layerscale_bwd_kernel, dim3(nblk, (cols / 8 + 255) / 256), dim3(256), 0, s, dy, (long)lddy, u, (long)ldu,
                      scale, du, (long)lddu, rows, cols, rpb, partial_ws);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial_ws, nblk, cols, dscale);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial_ws, nblk, cols, dscale, (float*)nullptr);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }
@@ -1007,7 +1052,7 @@ extern "C" int bl_colsum_bf16(const bl_bf16* a, int64_t lda, int32_t rows, int32
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, (cols / 8 + 63) / 64), dim3(256), 0, s, a, (long)lda, rows, cols,
                      rpb, partial_ws);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial_ws, nblk, cols, out);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial_ws, nblk, cols, out, (float*)nullptr);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }
@@ -1138,7 +1183,7 @@ extern "C" int bl_gemm_tn_small_bf16(const bl_bf16* P, int64_t ldp, const bl_bf1
   switch (R) { BL_TN(64) BL_TN(128) BL_TN(192) }
 #undef BL_TN
   if (splits > 1)
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)((stride + 63) / 64)), dim3(256), 0, s, partial_ws, splits, (int)stride, C);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((int)((stride + 63) / 64)), dim3(256), 0, s, partial_ws, splits, (int)stride, C, (float*)nullptr);
   BL_CHECK_LAUNCH();
   return BL_OK;
 }
