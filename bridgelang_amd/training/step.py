@@ -17,6 +17,8 @@ MI355X-first choices (DESIGN.md "Training step"):
 """
 from __future__ import annotations
 
+import contextlib
+
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -514,9 +516,23 @@ class TrainStep:
         self._vkey = vkey
         self._vseq_fwd = [vkey(tw, i) for tw in towers for i in range(-1, tw.dims.n_run)]
         self._vseq_bwd = [vkey(tw, i) for tw in towers for i in list(range(tw.dims.n_run - 1, -1, -1)) + [-1]]
+        # The two towers are independent between the pixels and the projector (forward) and between the projector's input
+        # gradient and their own weight gradients (backward): on ONE un-sharded GPU without adapters the second tower's plans
+        # run on a side stream inside the same graph, as in the inference engine (their K ≈ 1 K GEMMs pay ≈ 14 µs of launch
+        # + ramp + epilogue per 25 µs main loop and fill 130–270 of 256 CUs). The side tower gets its own scratch (split-K
+        # workspace, column-sum and norm partials); activations and gradients are per tower anyway. With ranks to reduce
+        # over, sharded parameters, LoRA or fp8 the plans stay one list. BL_TRAIN_VISION_STREAMS=0: single stream (A/B).
+        self._vis2 = (self.train_vision and len(towers) == 2 and not self.comm.active and not shard_params and lora is None
+                      and not fp8 and os.environ.get("BL_TRAIN_VISION_STREAMS", "1") != "0")
+        self._vis_stream = torch.cuda.Stream(device=dev) if self._vis2 else None
+        self._scratch2 = (dict(ws=torch.empty_like(self.ws), col_ws=torch.empty_like(self.col_ws), norm_ws=torch.empty_like(self.norm_ws))
+                          if self._vis2 else None)
         self.vision_forward_ops: List[Op] = []
-        for tw, sv, col in zip(towers, self.vis, (0, d.dino.dim)):
-            self.vision_forward_ops += self._plan_tower_forward(tw, col, sv)
+        self._vfwd_tower: List[List[Op]] = []
+        for ti, (tw, sv, col) in enumerate(zip(towers, self.vis, (0, d.dino.dim))):
+            with self._side_scratch(ti == 1):
+                self._vfwd_tower.append(self._plan_tower_forward(tw, col, sv))
+            self.vision_forward_ops += self._vfwd_tower[-1]
         self.forward_ops = self._plan_forward()
         self.tn_ws = z(8 << 20, dtype=torch.float32) if lora is not None else None
         self._ready: List[Tuple[int, str]] = []      # (number of backward ops enqueued, bucket key complete at that point)
@@ -1215,8 +1231,12 @@ class TrainStep:
             if head:
                 plan += [self._u_release("projector"), self._u_flush("projector")]
             if self.train_vision:
-                for tw, sv, col in zip((w.dino, w.siglip), self.vis, (0, d.dino.dim)):
-                    plan += self._plan_tower_backward(tw, col, sv, len(plan))
+                self._bwd_tower_at = [len(plan)]                   # [start of tower 0, start of tower 1]: see _vis2
+                for ti, (tw, sv, col) in enumerate(zip((w.dino, w.siglip), self.vis, (0, d.dino.dim))):
+                    if ti:
+                        self._bwd_tower_at.append(len(plan))
+                    with self._side_scratch(ti == 1):
+                        plan += self._plan_tower_backward(tw, col, sv, len(plan))
         return plan
 
     # ---- vision towers in training form (timm VisionTransformer blocks) ---------------------------
@@ -1420,19 +1440,45 @@ class TrainStep:
         tg[:, :-1] = full[:, 1:]                                                       # position t predicts token t+1
         self.targets.copy_(tg.view(-1))
 
-    def _replay(self, key: str, plan: List[Op], graph: bool) -> None:
+    @contextlib.contextmanager
+    def _side_scratch(self, on: bool):
+        """While the SECOND tower's plans are built: the scratch buffers its ops bind are the side stream's own."""
+        if not (on and self._vis2):
+            yield
+            return
+        keep = {k: getattr(self, k) for k in self._scratch2}
+        for k, v in self._scratch2.items():
+            setattr(self, k, v)
+        try:
+            yield
+        finally:
+            for k, v in keep.items():
+                setattr(self, k, v)
+
+    def _run_forked(self, main_ops: List[Op], side_ops: List[Op]) -> None:
+        """main_ops on the current stream, side_ops on the vision side stream, joined at the end (fork / join with stream
+        waits, which HIP-graph capture records as parallel branches)."""
+        main = torch.cuda.current_stream()
+        self._vis_stream.wait_stream(main)
+        with torch.cuda.stream(self._vis_stream):
+            ops.run_all(side_ops)
+        ops.run_all(main_ops)
+        main.wait_stream(self._vis_stream)
+
+    def _replay(self, key: str, plan, graph: bool) -> None:
         if self._materialized:
             raise RuntimeError("materialize_params() ended this step object's training (its plans address the gather slots)")
+        run = plan if callable(plan) else (lambda: ops.run_all(plan))      # a callable issues its own (forked) launches
         if not graph or (self.shard_params and key in ("vfwd", "fwd", "bwd")):      # per-unit collectives stay out of HIP graphs
-            ops.run_all(plan)
+            run()
             return
         gr = self._graphs.get(key)
         if gr is None:
-            ops.run_all(plan)                                      # warm (lazy hipFuncSetAttribute etc.) outside capture
+            run()                                                  # warm (lazy hipFuncSetAttribute etc.) outside capture
             torch.cuda.synchronize()
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
-                ops.run_all(plan)
+                run()
             self._graphs[key] = gr
         gr.replay()
 
@@ -1440,7 +1486,9 @@ class TrainStep:
         """Vision towers (frozen) → projector → decoder → loss. Returns the device scalar loss."""
         if self.lora is not None and self.lora.dropout > 0.0:
             self._drop_seed.add_(1)            # a fresh mask per forward pass; the backward pass recomputes it from the same value
-        if self.train_vision:
+        if self.train_vision and self._vis2:
+            self._replay("vfwd", lambda: self._run_forked(self._vfwd_tower[0], self._vfwd_tower[1]), graph)
+        elif self.train_vision:
             self._replay("vfwd", self.vision_forward_ops, graph)
         else:
             self._vis.run_vision()
@@ -1452,7 +1500,12 @@ class TrainStep:
         reduce-scatter on a side stream as soon as its last wgrad is enqueued (overlapping the rest of the backward)."""
         st, lay = self.store, self.store.layout
         if not self.comm.active:
-            self._replay("bwd", self.backward_ops, graph)
+            if self._vis2 and getattr(self, "_bwd_tower_at", None) and len(self._bwd_tower_at) == 2:
+                a, b = self._bwd_tower_at
+                bo = self.backward_ops
+                self._replay("bwd", lambda: (ops.run_all(bo[:a]), self._run_forked(bo[a:b], bo[b:])), graph)
+            else:
+                self._replay("bwd", self.backward_ops, graph)
             if self.shard_params:                                  # the per-layer gradient flushes ran on the side stream
                 torch.cuda.current_stream().wait_stream(self._comm_stream)
             return
