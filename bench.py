@@ -48,7 +48,7 @@ def newest_pmc(name: str):
 def pmc_provenance(path, pj: dict) -> dict:
     c = pj.get("collected") or {}
     return {"file": str(path.relative_to(ROOT)), "collected_at_commit": c.get("commit"), "collected_on": c.get("date"),
-            "round": c.get("round"), "note": "GEMM kernels changed since that commit => re-run the --pmc passes (tools/pmc_gemm.py)"}
+            "round": c.get("round"), "note": "valid while the tile GEMM kernels (gemm256s / gemm288s / tail) are as at that commit; otherwise re-run the --pmc passes (tools/pmc_gemm.py)"}
 sys.path.insert(0, str(ROOT))
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 (guides/MI355X_MICROARCH.md)

@@ -520,10 +520,11 @@ class TrainStep:
         # gradient and their own weight gradients (backward): on ONE un-sharded GPU without adapters the second tower's plans
         # run on a side stream inside the same graph, as in the inference engine (their K ≈ 1 K GEMMs pay ≈ 14 µs of launch
         # + ramp + epilogue per 25 µs main loop and fill 130–270 of 256 CUs). The side tower gets its own scratch (split-K
-        # workspace, column-sum and norm partials); activations and gradients are per tower anyway. With ranks to reduce
-        # over, sharded parameters, LoRA or fp8 the plans stay one list. BL_TRAIN_VISION_STREAMS=0: single stream (A/B).
-        self._vis2 = (self.train_vision and len(towers) == 2 and not self.comm.active and not shard_params and lora is None
-                      and not fp8 and os.environ.get("BL_TRAIN_VISION_STREAMS", "1") != "0")
+        # workspace, column-sum / norm / adapter-gradient partials); activations and gradients are per tower anyway. With ranks
+        # to reduce over, sharded parameters, fp8 or LoRA dropout the plans stay one list. BL_TRAIN_VISION_STREAMS=0: single stream (A/B).
+        self._vis2 = (self.train_vision and len(towers) == 2 and not self.comm.active and not shard_params and not fp8
+                      and (lora is None or lora.dropout == 0.0)      # the dropout buffers serve one adapted linear at a time
+                      and os.environ.get("BL_TRAIN_VISION_STREAMS", "1") != "0")
         self._vis_stream = torch.cuda.Stream(device=dev) if self._vis2 else None
         self._scratch2 = (dict(ws=torch.empty_like(self.ws), col_ws=torch.empty_like(self.col_ws), norm_ws=torch.empty_like(self.norm_ws))
                           if self._vis2 else None)
@@ -535,6 +536,8 @@ class TrainStep:
             self.vision_forward_ops += self._vfwd_tower[-1]
         self.forward_ops = self._plan_forward()
         self.tn_ws = z(8 << 20, dtype=torch.float32) if lora is not None else None
+        if self._vis2 and self.tn_ws is not None:
+            self._scratch2["tn_ws"] = torch.empty_like(self.tn_ws)
         self._ready: List[Tuple[int, str]] = []      # (number of backward ops enqueued, bucket key complete at that point)
         self.backward_ops = self._plan_backward()
         self.repack_ops = self._plan_repack()
