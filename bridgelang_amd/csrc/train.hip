@@ -900,7 +900,8 @@ static int norm_backward(const bl_bf16* x, int64_t ldx, const bl_bf16* w, const 
 #define BL_CASE_DRL(N) case N: hipLaunchKernelGGL((norm_bwd_kernel<N, LN, true>), dim3(nblk), dim3(256), 0, s, x, (long)ldx, w, dy, \
     (long)lddy, dres, (long)lddres, dx, (long)lddx, partial_ws, rows, dim, eps, rpb); break;
   // dres through LDS: one row per wave (nch >= 5), whole 512-column chunks, 32-bit buffer offsets. BL_NORM_BWD_DRL=0: A/B.
-  static const int drl_on = getenv("BL_NORM_BWD_DRL") ? atoi(getenv("BL_NORM_BWD_DRL")) : 1;
+  const char* e_drl = getenv("BL_NORM_BWD_DRL");      // read per call: the tests switch it inside one process
+  const int drl_on = e_drl ? atoi(e_drl) : 1;
   const bool drl = drl_on && !LN && dres && nch >= 5 && dim == nch * 512 && (long)rows * lddres * 2 < (1L << 32) && bl_aligned16(dres);
   if (drl) {
     switch (nch) { BL_CASE_DRL(5) BL_CASE_DRL(6) BL_CASE_DRL(7) BL_CASE_DRL(8) BL_CASE_DRL(9) BL_CASE_DRL(10) default: return BL_E_SHAPE; }

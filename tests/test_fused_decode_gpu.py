@@ -106,6 +106,26 @@ def test_skinny_rows_bit_identical_to_skinny(dev, M, N, K):
     close_bf16(out, R.linear(P, a, w), "skinny rows vs oracle")
 
 
+@pytest.mark.parametrize("M,N,K", [(96, 12288, 4096), (48, 22016, 1024), (96, 32064, 1024)])
+def test_rows_stream_equals_mid_kernel(dev, M, N, K, monkeypatch):
+    """The wide layers of the merged decode iteration run on gemm_rows_stream_kernel (weights HBM → VGPR, rows staged once
+    per workgroup); BL_ROWS_STREAM=0 keeps them on gemm_mid_kernel<SK>. Both walk the skinny order: equal bit for bit,
+    with and without the K split over two workgroups (workspace given / not given)."""
+    from bridgelang_amd import ops
+    a, w = rand_bf16((M, K), 1), rand_bf16((N, K), 2, 0.05)
+    A, W = dv(a, dev), pk(w, dev)
+    ws = torch.empty(4 * M * N * 4, dtype=torch.uint8, device=dev)
+    got = {}
+    for on in ("0", "1"):
+        monkeypatch.setenv("BL_ROWS_STREAM", on)
+        for wsp in (None, ws):
+            out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=dev)
+            ops.gemm(A, W, out, ops.EPI_NONE, skinny_rows=True, workspace=wsp)
+            got[on, wsp is None] = out.cpu()
+    assert torch.equal(got["0", True], got["1", True]) and torch.equal(got["0", False], got["1", False])
+    assert torch.equal(got["1", True], got["1", False])
+
+
 @pytest.mark.parametrize("rows,K", [(96, 4096), (16, 512), (33, 1536), (5, 11008), (50, 5120), (128, 1024), (17, 13824)])
 def test_rmsnorm_skinny_equals_fused_norm(dev, rows, K):
     """bl_rmsnorm_skinny_bf16 + a GEMM == the skinny GEMM's fused a_norm, bit for bit (probed through an identity-like

@@ -56,6 +56,24 @@ def test_rmsnorm_backward(dev, rows, dim):
     grad_close(dx, xr.grad, "rmsnorm dx")
 
 
+@pytest.mark.parametrize("rows,dim", [(333, 4096), (64, 5120), (700, 2560)])
+def test_rmsnorm_backward_dres_through_lds_is_bit_identical(dev, rows, dim, monkeypatch):
+    """The decoder's RMSNorm backward carries the residual-stream gradient row through LDS (LDS-DMA under the reduction
+    passes) instead of loading it inside the output pass: same arithmetic, so dx and dw must equal the plain form
+    (BL_NORM_BWD_DRL=0) bit for bit — ragged last block, 13B width (one workgroup per CU), 2560 = five whole chunks."""
+    from bridgelang_amd import train_ops as T
+    x, w, dy, dres = rand_bf16((rows, dim), 1, 2.0), P.rb(rand_bf16((dim,), 2, 0.02) + 1), rand_bf16((rows, dim), 3), rand_bf16((rows, dim), 4)
+    got = {}
+    for on in ("0", "1"):
+        monkeypatch.setenv("BL_NORM_BWD_DRL", on)
+        dx = torch.empty(rows, dim, dtype=torch.bfloat16, device=dev)
+        dw = torch.empty(dim, device=dev)
+        ws = torch.empty(((rows + 15) // 16) * dim, device=dev)
+        T.rmsnorm_backward(dv(x, dev), dv(w, dev), dv(dy, dev), dx, dw, ws, 1e-6, dres=dv(dres, dev))
+        got[on] = (dx.cpu(), dw.cpu())
+    assert torch.equal(got["0"][0], got["1"][0]) and torch.equal(got["0"][1], got["1"][1])
+
+
 def test_swiglu_gelu_rope_backward(dev):
     from bridgelang_amd import train_ops as T
     M, I = 37, 1536

@@ -140,6 +140,34 @@ def test_graph_replay_equals_eager_over_steps(dev, stage):
     assert torch.equal(out[False][1], out[True][1])
 
 
+@pytest.mark.parametrize("lora_on", [False, True])
+def test_two_stream_vision_towers_equal_one_stream(dev, lora_on, monkeypatch):
+    """On one un-sharded GPU the second tower's forward / backward plans run on a side stream (own scratch) inside the
+    step's graphs: same kernels on the same data — losses, gradient norms and every master weight must equal the
+    single-stream step (BL_TRAIN_VISION_STREAMS=0) bit for bit, for the full fine-tune and for LoRA."""
+    from bridgelang_amd.training.lora import LoraAdapters
+    from bridgelang_amd.training.step import TrainStep
+    from bridgelang_amd.weights import allocate, tiny_dims
+    dims = tiny_dims()
+    out = {}
+    for streams in ("0", "1"):
+        monkeypatch.setenv("BL_TRAIN_VISION_STREAMS", streams)
+        w = allocate(dims, dev).fill_synthetic(seed=5)
+        lora = LoraAdapters(w, r=8, alpha=16, seed=3) if lora_on else None
+        ts = TrainStep(w, "lora" if lora_on else "vla-full-train", 2, 18, max_grad_norm=1.0, weight_decay=0.1, lora=lora)
+        assert ts._vis2 == (streams == "1")
+        log = []
+        for step in range(3):
+            ids, mask, labels, pv = make_batch(dims, 2, 18, seed=40 + step)
+            ts.set_batch(ids, mask, pv, labels)
+            loss, norm = ts.step(1e-3, graph=True)
+            log.append((loss.item(), norm.item()))
+        out[streams] = (log, ts.store.full_master().cpu())
+    print(out["0"][0], out["1"][0])
+    assert out["0"][0] == out["1"][0]
+    assert torch.equal(out["0"][1], out["1"][1])
+
+
 @pytest.mark.parametrize("stage", ["vla-train", "vla-full-train"])
 def test_recompute_equals_saved_activations(dev, stage):
     """Activation recomputation (the reference's checkpointing of the decoder layers, fsdp.py:171-183) replays each
