@@ -517,12 +517,13 @@ class TrainStep:
         self._vseq_fwd = [vkey(tw, i) for tw in towers for i in range(-1, tw.dims.n_run)]
         self._vseq_bwd = [vkey(tw, i) for tw in towers for i in list(range(tw.dims.n_run - 1, -1, -1)) + [-1]]
         # The two towers are independent between the pixels and the projector (forward) and between the projector's input
-        # gradient and their own weight gradients (backward): on ONE un-sharded GPU without adapters the second tower's plans
-        # run on a side stream inside the same graph, as in the inference engine (their K ≈ 1 K GEMMs pay ≈ 14 µs of launch
-        # + ramp + epilogue per 25 µs main loop and fill 130–270 of 256 CUs). The side tower gets its own scratch (split-K
-        # workspace, column-sum / norm / adapter-gradient partials); activations and gradients are per tower anyway. With ranks
-        # to reduce over, sharded parameters, fp8 or LoRA dropout the plans stay one list. BL_TRAIN_VISION_STREAMS=0: single stream (A/B).
-        self._vis2 = (self.train_vision and len(towers) == 2 and not self.comm.active and not shard_params and not fp8
+        # gradient and their own weight gradients (backward): with un-sharded parameters the second tower's plans run on a
+        # side stream inside the same graph, as in the inference engine — their K ≈ 1 K GEMMs pay ≈ 14 µs of launch + ramp +
+        # epilogue per 25 µs main loop and fill 130–270 of 256 CUs. (The backward only on one GPU: with ranks to reduce over
+        # it is issued bucket by bucket on one stream, see backward().) The side tower gets its own scratch (split-K
+        # workspace, column-sum / norm / adapter-gradient partials); activations and gradients are per tower anyway. With
+        # sharded parameters, fp8 or LoRA dropout the plans stay one list. BL_TRAIN_VISION_STREAMS=0: single stream (A/B).
+        self._vis2 = (self.train_vision and len(towers) == 2 and not shard_params and not fp8
                       and (lora is None or lora.dropout == 0.0)      # the dropout buffers serve one adapted linear at a time
                       and os.environ.get("BL_TRAIN_VISION_STREAMS", "1") != "0")
         self._vis_stream = torch.cuda.Stream(device=dev) if self._vis2 else None
