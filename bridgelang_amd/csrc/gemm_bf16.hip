@@ -556,10 +556,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mid_kernel(GemmArgs p) {
 // previous chunk is issued a quarter at a time BEHIND each k-step's MFMAs: a load that stalls at issue because the CU's
 // request queue is full then stalls under MFMAs that are already in the pipe (−5 % against issuing it in one block).
 // Slices, the binary-counter fold and the grid.y split are gemm_mid_kernel<SK>'s: results are bit-identical to it and to
-// gemm_skinny_kernel. ALIGNED: fold_ks is a multiple of GS (K = 4096 / 5120: slices end on chunk boundaries) — the
-// slice-boundary test runs once per chunk.
+// gemm_skinny_kernel. fold_ks must be a multiple of GS (K a multiple of 1024: slices end on chunk boundaries, the
+// slice-boundary test runs once per chunk) — the launcher sends everything else to the mid kernel.
 // ======================================================================================================================
-template <int EPI, int NWV, int SK, bool ALIGNED>
+template <int EPI, int NWV, int SK>
 __global__ __launch_bounds__(NWV * 64) void gemm_rows_stream_kernel(GemmArgs p, int n_tiles) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int MR = 6, GS = 4, NWB = 4;
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_rows_stream_kernel(GemmArgs p, 
         const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wbuf[SLOT][s2]);                                     \
         _Pragma("unroll") for (int j = 0; j < MR; ++j)                                                        \
           acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[s2 & 1][j], acc[j], 0, 0, 0);               \
-        if (SK > 1 && (!ALIGNED || s2 == GS - 1) && kidx + 1 == fold_next) {                                  \
+        if (SK > 1 && s2 == GS - 1 && kidx + 1 == fold_next) {   /* slices end on chunk boundaries */        \
           bool parked = false;                                                                                \
           /* opaque to the optimiser, as in gemm_mid_kernel: no speculated VALU read of the accumulators */    \
           _Pragma("unroll") for (int j = 0; j < MR; ++j) asm volatile("" : "+v"(acc[j]));                     \
@@ -1592,11 +1592,11 @@ template <int EPI, int NWV, int SK>
 int launch_rs(const GemmArgs& p, hipStream_t s, int n_tiles) {
   static bool done = false;
   if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_stream_kernel<EPI, NWV, SK, true>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_stream_kernel<EPI, NWV, SK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES) != hipSuccess) return BL_E_LAUNCH;
     done = true;
   }
-  hipLaunchKernelGGL((gemm_rows_stream_kernel<EPI, NWV, SK, true>), dim3((n_tiles + NWV - 1) / NWV, 8 / SK), dim3(NWV * 64),
+  hipLaunchKernelGGL((gemm_rows_stream_kernel<EPI, NWV, SK>), dim3((n_tiles + NWV - 1) / NWV, 8 / SK), dim3(NWV * 64),
                      RS_LDS_BYTES, s, p, n_tiles);
   return BL_OK;
 }
