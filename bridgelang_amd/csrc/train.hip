@@ -407,21 +407,35 @@ __global__ void scale_residual_kernel(const uint16_t* u, long ldu, const uint16_
     *(u32x4_t*)(y + r * ldy + ch * 8) = pack8(o);
   }
 }
+// One thread per 8 columns, blockDim.x = cols / 8 threads per row block (≤ 256), four rows in flight per thread (their loads
+// are issued before any is consumed). Round 4: 64-row blocks of a 256-thread workgroup whose upper half returned at once
+// (cols = 1024 → 128 live threads) were 131 two-wave workgroups on 256 CUs, one dependent row after the other: 1.3 TB/s.
 __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const uint16_t* dy, long lddy, const uint16_t* u, long ldu,
                                                              const uint16_t* ls, uint16_t* du, long lddu, int rows,
                                                              int cols, int rows_per_block, float* partial) {
-  const int col8 = (blockIdx.y * 256 + threadIdx.x) * 8;
+  const int col8 = (blockIdx.y * blockDim.x + threadIdx.x) * 8;
   if (col8 >= cols) return;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s[8];
   unpack8(*(const u32x4_t*)(ls + col8), s);
   const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  for (int r = r0; r < r1; ++r) {
-    float g[8], a[8], o[8];
-    unpack8(*(const u32x4_t*)(dy + (long)r * lddy + col8), g);
-    unpack8(*(const u32x4_t*)(u + (long)r * ldu + col8), a);
+  for (int r = r0; r < r1; r += 4) {
+    u32x4_t gq[4], aq[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { acc[e] += g[e] * a[e]; o[e] = g[e] * s[e]; }
-    *(u32x4_t*)(du + (long)r * lddu + col8) = pack8(o);
+    for (int k = 0; k < 4; ++k) {
+      const int rr = min(r + k, r1 - 1);
+      gq[k] = *(const u32x4_t*)(dy + (long)rr * lddy + col8);
+      aq[k] = *(const u32x4_t*)(u + (long)rr * ldu + col8);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (r + k >= r1) break;
+      float g[8], a[8], o[8];
+      unpack8(gq[k], g);
+      unpack8(aq[k], a);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { acc[e] += g[e] * a[e]; o[e] = g[e] * s[e]; }
+      *(u32x4_t*)(du + (long)(r + k) * lddu + col8) = pack8(o);
+    }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) partial[(long)blockIdx.x * cols + col8 + e] = acc[e];
@@ -947,10 +961,15 @@ extern "C" int bl_layerscale_backward_bf16(const bl_bf16* dy, int64_t lddy, cons
                                            int64_t partial_ws_floats, int32_t rows, int32_t cols, void* stream) {
   if (!dy || !u || !scale || !du || !dscale || !partial_ws) return BL_E_ARG;
   if (rows <= 0 || cols <= 0 || (cols % 8) || (lddy % 8) || (ldu % 8) || (lddu % 8)) return BL_E_SHAPE;
-  const int rpb = 64, nblk = (rows + rpb - 1) / rpb;
-  if (partial_ws_floats < (int64_t)nblk * cols) return BL_E_SHAPE;
+  int rpb = 16;                                  // as many row blocks as the partial workspace holds (16 rows: 522 blocks at 8352)
+  while ((int64_t)((rows + rpb - 1) / rpb) * cols > partial_ws_floats) {
+    rpb *= 2;
+    if (rpb > 4096) return BL_E_SHAPE;
+  }
+  const int nblk = (rows + rpb - 1) / rpb;
+  const int tpb = std::min(256, (cols / 8 + 63) / 64 * 64);       // threads per block: the row's 8-column groups, whole waves
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(layerscale_bwd_kernel, dim3(nblk, (cols / 8 + 255) / 256), dim3(256), 0, s, dy, (long)lddy, u, (long)ldu,
+  hipLaunchKernelGGL(layerscale_bwd_kernel, dim3(nblk, (cols / 8 + tpb - 1) / tpb), dim3(tpb), 0, s, dy, (long)lddy, u, (long)ldu,
                      scale, du, (long)lddu, rows, cols, rpb, partial_ws);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial_ws, nblk, cols, dscale, (float*)nullptr);
   BL_CHECK_LAUNCH();
