@@ -17,8 +17,12 @@ __device__ __forceinline__ float bf2f(uint16_t v) { return __builtin_bit_cast(fl
 // Plain cast lowers to v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN-preserving) on gfx950.
 __device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }  // round through bf16
+// ONE v_cvt_pk_bf16_f32 for the pair (the two-scalar-casts form cost two converts + shift + or; same rounding)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ float bflo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }

@@ -295,6 +295,140 @@ __global__ __launch_bounds__(WM * 128) void gemm_tail_kernel(GemmArgs p) {
 #endif
 }
 
+// ======================================================================================================================
+// ring kernel with TWO waves per SIMD (round 4): the tail kernel's stand-alone mode (one round of BM × BN = 160 × 128 tiles,
+// NST-stage LDS-DMA ring, counted vmcnt, one barrier per K-step) run by 8 waves — 2 along m × 4 along n, 80 × 32 outputs
+// each. With one wave per SIMD the wave that issues a ring slot's LDS-DMA pieces (≈ 60 issue cycles per 1-KiB piece) is the
+// only one that could issue MFMAs there, so a K-step took pieces + fragment reads + MFMAs back to back (ISA: 9 pieces, 18
+// ds_read_b128, lgkmcnt(0), 40 MFMAs: ≈ 0.82 µs for 640 cycles of matrix work). Here every wave carries half the MFMAs and
+// half the pieces of its SIMD, the pieces are spread through the wave's MFMAs (sched_barrier-pinned groups), and the
+// partner wave's MFMAs issue while this wave sits in a piece's issue. The 20 activation pieces do not divide by 8 waves:
+// waves 4–7 issue a third, out-of-range piece (zero-fill, no memory request) into a dump KiB behind the ring, which keeps
+// the loop branch-free and the counted vmcnt the same for every wave. K order per output = every other tile kernel's.
+// ======================================================================================================================
+template <int EPI, int BM, int BN, int NST>
+__global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int WNW = 4, NWAVE = 8, TM = BM / 2, TN = BN / WNW, MT = TM / 16, NT = TN / 16;
+  constexpr int APIECES = BM / 8, WPIECES = BN / 8;
+  constexpr int APW = (APIECES + NWAVE - 1) / NWAVE, WPW = WPIECES / NWAVE, LPS = APW + WPW;
+  static_assert(TM % 16 == 0 && TN % 16 == 0 && WPIECES % NWAVE == 0, "tile shape");
+  constexpr int A_BYTES = BM * ROW_BYTES, BUF_BYTES = A_BYTES + BN * ROW_BYTES, DUMP = NST * BUF_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // NST × BUF_BYTES + 1 KiB dump
+
+  const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  const int m0 = (lin / p.tiles_n) * BM, n0 = (lin % p.tiles_n) * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int kt32 = p.K >> 5;
+
+  const unsigned a_bytes = (unsigned)min((long)p.M * p.lda * 2, 0xffffffffL);
+  const unsigned w_bytes = (unsigned)min((long)p.N * p.K * 2, 0xffffffffL);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
+
+  const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
+  unsigned voffA[APW], voffW[WPW];
+  int ldsA[APW];                       // slot-relative LDS byte offset of this wave's j-th activation piece (wave-uniform)
+#pragma unroll
+  for (int j = 0; j < APW; ++j) {
+    const int pi = j * NWAVE + wave;
+    const bool real = pi < APIECES;
+    voffA[j] = real ? (unsigned)(((long)(m0 + pi * 8 + prow) * p.lda) * 2 + pchunk * 16) : 0xfffffff0u;
+    ldsA[j] = real ? pi * 1024 : -1;
+  }
+#pragma unroll
+  for (int j = 0; j < WPW; ++j) {   // weight block b = j*NWAVE + wave: n-tile b >> 1, k-step b & 1
+    const int blk = j * NWAVE + wave;
+    voffW[j] = (unsigned)(((long)(n0 / 16 + (blk >> 1)) * kt32 + (blk & 1)) * 1024 + lane * 16);
+  }
+  // piece `pc` (0 … LPS-1) of this wave for K-tile KT into ring slot BUF
+#define BL_PIECE(BUF, KT, PC)                                                                                     \
+  do {                                                                                                            \
+    char* base__ = smem + (BUF) * BUF_BYTES;                                                                      \
+    if ((PC) < APW) {                                                                                             \
+      const int ja__ = (PC) < APW ? (PC) : 0;                                                                     \
+      BL_GLDS(rsA, ldsA[ja__] >= 0 ? base__ + ldsA[ja__] : smem + DUMP, voffA[ja__], (KT) * 128);                 \
+    } else {                                                                                                      \
+      const int jw__ = (PC) >= APW ? (PC) - APW : 0;                                                              \
+      BL_GLDS(rsW, base__ + A_BYTES + (jw__ * NWAVE + wave) * 1024, voffW[jw__], (KT) * 2048);                    \
+    }                                                                                                             \
+  } while (0)
+
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int c0 = lg ^ (lane & 7);
+  const int offA = (wm * TM + l15) * ROW_BYTES;
+  const int offW = A_BYTES + (wn * NT) * 2048 + lane * 16;   // block (wn*NT + i)*2 + ks
+
+  f32x4_t acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+#pragma unroll
+  for (int s2 = 0; s2 < NST - 1; ++s2) {
+    const int kt0 = min(s2, nk - 1);
+#pragma unroll
+    for (int pc = 0; pc < LPS; ++pc) BL_PIECE(s2, kt0, pc);
+  }
+  static_assert((NST - 2) * LPS <= 63 && NST >= 4, "counted vmcnt range / ring depth");
+  constexpr int NMF = 2 * NT * MT, EVERY = NMF / LPS;          // one piece every EVERY MFMAs
+  constexpr int NRD = 2 * (NT + MT), RPG = (NRD + LPS - 1) / LPS;   // fragment reads per K-tile, per group
+  static_assert(EVERY >= 1, "more DMA pieces than MFMAs");
+  // Two fragment register sets: the reads of K-tile kt+1 are issued among the MFMAs of K-tile kt (after the barrier that
+  // says kt+1 has landed), so no wave ever waits on LDS at the head of a K-step — with one set all eight waves read their
+  // 14 fragments right behind the barrier (≈ 450 LDS cycles per CU with no MFMA in flight: 0.58 µs per K-step measured).
+  // The loop is unrolled by two K-steps for the set swap (the launcher requires K % 128 == 0).
+  bf16x8_t wf[2][2][NT], af[2][2][MT];
+#define BL_READ(SET, BASE, RI)                                                                                   \
+  do {                                                                                                           \
+    const int ks__ = (RI) / (NT + MT), e__ = (RI) % (NT + MT);                                                   \
+    if (e__ < NT) wf[SET][ks__][e__ < NT ? e__ : 0] = *(const bf16x8_t*)((BASE) + offW + e__ * 2048 + ks__ * 1024);   \
+    else af[SET][ks__][e__ >= NT ? e__ - NT : 0] =                                                               \
+        *(const bf16x8_t*)((BASE) + offA + (e__ - NT) * 16 * ROW_BYTES + ((c0 ^ (ks__ * 4)) << 4));              \
+  } while (0)
+#define BL_KSTEP(CUR, NXT, KT)                                                                                   \
+  do {                                                                                                           \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 3) * LPS) : "memory");   /* K-tile KT+1 landed (my pieces) */ \
+    __builtin_amdgcn_s_barrier();   /* … for every wave; every wave has its fragments of K-tile KT-1 and older */ \
+    const char* nb__ = smem + (((KT) + 1) % NST) * BUF_BYTES;                                                    \
+    const int nslot__ = ((KT) + NST - 1) % NST;                      /* the slot of K-tile KT-1 */               \
+    const int nkt__ = min((KT) + NST - 1, nk - 1);                                                               \
+    _Pragma("unroll") for (int g = 0; g < LPS; ++g) {                                                            \
+      BL_PIECE(nslot__, nkt__, g);                                                                               \
+      _Pragma("unroll") for (int ri = g * RPG; ri < ((g + 1) * RPG < NRD ? (g + 1) * RPG : NRD); ++ri)           \
+          BL_READ(NXT, nb__, ri);                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                         \
+      _Pragma("unroll") for (int idx = g * EVERY; idx < ((g + 1 < LPS) ? (g + 1) * EVERY : NMF); ++idx) {        \
+        const int ks = idx / (NT * MT), i = (idx / MT) % NT, j = idx % MT;                                       \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[CUR][ks][i], af[CUR][ks][j], acc[i][j], 0, 0, 0); \
+      }                                                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                         \
+    }                                                                                                            \
+  } while (0)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPS) : "memory");   // K-tile 0 landed (this wave's pieces)
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int ri = 0; ri < NRD; ++ri) BL_READ(0, smem, ri);
+  for (int kt = 0; kt < nk; kt += 2) {
+    BL_KSTEP(0, 1, kt);
+    BL_KSTEP(1, 0, kt + 1);
+  }
+#undef BL_KSTEP
+#undef BL_READ
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus stages must not outlive the workgroup's LDS allocation
+#undef BL_PIECE
+  int ncol[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) ncol[i] = n0 + wn * TN + i * 16 + lg * 4;
+  epilogue_tile<EPI, NT, MT>(p, m0 + wm * TM + l15, ncol, m0 + BM, n0 + BN, acc);
+#endif
+}
+
 // out(m, n..n+3) = epilogue(Σ_slices slab[slice][m][n..n+3]) for the split-K form of the 128 kernel
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm128_splitk_reduce_kernel(GemmArgs p) {
@@ -1029,9 +1163,9 @@ __global__ __launch_bounds__(512) void gemm288s_kernel(GemmArgs p) {
 #define BL_EPILOGUE()                                                                                     \
   do {                                                                                                    \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
-      _Pragma("unroll") for (int j = 0; j < 9; ++j)                                                       \
-        epilogue_store4<EPI>(p, m0 + wm * 144 + j * 16 + l15, n0 + wn * 64 + i * 16 + lg * 4, acc[i][j]); \
+    const int ncol__[4] = {n0 + wn * 64 + lg * 4, n0 + wn * 64 + 16 + lg * 4, n0 + wn * 64 + 32 + lg * 4,      \
+                           n0 + wn * 64 + 48 + lg * 4};                                                   \
+    epilogue_tile<EPI, 4, 9>(p, m0 + wm * 144 + l15, ncol__, m0 + 288, n0 + 256, acc);                    \
   } while (0)
 
   f32x4_t acc[4][9];
@@ -1481,11 +1615,10 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) *(f32x4_t*)(dst + (long)(i * 8 + j) * 512 * 4) = acc[i][j]; \
     } else {                                                                                              \
+      int ncol__[4];                                                                                      \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                     \
-          epilogue_store4<EPI>(p, m0 + wm * 128 + j * 16 + l15,                                           \
-                               TN ? n0 + (i >> 1) * 128 + wn * 32 + (i & 1) * 16 + lg * 4                 \
-                                  : n0 + wn * 64 + i * 16 + lg * 4, acc[i][j]);                           \
+        ncol__[i] = TN ? n0 + (i >> 1) * 128 + wn * 32 + (i & 1) * 16 + lg * 4 : n0 + wn * 64 + i * 16 + lg * 4; \
+      epilogue_tile<EPI, 4, 8>(p, m0 + wm * 128 + l15, ncol__, m0 + 256, n0 + 256, acc);                  \
     }                                                                                                     \
   } while (0)
 
@@ -1677,6 +1810,8 @@ int set_lds_attr() {
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * ROW_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tail_kernel<EPI, 160, 128, 4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 288 * ROW_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring8_kernel<EPI, 160, 128, 4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 288 * ROW_BYTES + 1024) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mid2_kernel<EPI, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             3 * (160 * ROW_BYTES + 4096)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mid2_kernel<EPI, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1771,7 +1906,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
       p.tiles_m = (p.M + 159) / 160;
       p.tiles_n = (p.N + 127) / 128;
       p.tail_base = -1;
-      hipLaunchKernelGGL((gemm_tail_kernel<EPI, 160, 128, 4>), dim3(t160), dim3(256), 4 * 288 * ROW_BYTES, s, p);
+      static const bool ring_w4 = getenv("BL_GEMM_RING160_W4") != nullptr;      // A/B aid: the one-wave-per-SIMD form
+      if (ring_w4 || (p.K % 128)) hipLaunchKernelGGL((gemm_tail_kernel<EPI, 160, 128, 4>), dim3(t160), dim3(256), 4 * 288 * ROW_BYTES, s, p);
+      else hipLaunchKernelGGL((gemm_ring8_kernel<EPI, 160, 128, 4>), dim3(t160), dim3(512), 4 * 288 * ROW_BYTES + 1024, s, p);
       BL_CHECK_LAUNCH();
       return BL_OK;
     }
