@@ -121,10 +121,11 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, int mrow, const
                                               f32x4_t (&acc)[NI][NJ]) {
   constexpr bool kHasBias = EPI == BL_EPI_BIAS || EPI == BL_EPI_BIAS_GELU || EPI == BL_EPI_BIAS_RES;
   constexpr bool kHasRes = EPI == BL_EPI_BIAS_RES || EPI == BL_EPI_RES;
-  constexpr bool kFast = EPI == BL_EPI_NONE || kHasBias || kHasRes || EPI == BL_EPI_SWIGLU;
+  constexpr bool kF32 = EPI == BL_EPI_F32 || EPI == BL_EPI_F32_BF16R;      // fp32 output (weight gradients, logits)
+  constexpr bool kFast = EPI == BL_EPI_NONE || kHasBias || kHasRes || EPI == BL_EPI_SWIGLU || kF32;
   if constexpr (kFast) {
     const bool plain = p.out_group == 0 && p.res_row_mod == 0 && m_end <= p.M && n_end <= p.N &&
-                       (long)p.M * p.ldc * 2 < (1L << 32) && (!kHasRes || (long)p.M * p.ldres * 2 < (1L << 32));
+                       (long)p.M * p.ldc * (kF32 ? 4 : 2) < (1L << 32) && (!kHasRes || (long)p.M * p.ldres * 2 < (1L << 32));
     if (plain) {
       u32x2_t bq[NI], sq[NI];
 #pragma unroll
@@ -150,7 +151,11 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, int mrow, const
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
           const f32x4_t a = acc[i][j];
-          if constexpr (EPI == BL_EPI_SWIGLU) {
+          if constexpr (kF32) {
+            f32x4_t o = a;
+            if constexpr (EPI == BL_EPI_F32_BF16R) o = (f32x4_t){rbf(a[0]), rbf(a[1]), rbf(a[2]), rbf(a[3])};
+            *(f32x4_t*)(cbase + (size_t)((m * ldc + (uint32_t)ncol[i]) * 4u)) = o;
+          } else if constexpr (EPI == BL_EPI_SWIGLU) {
             const float g0 = rbf(a[0]), u0 = rbf(a[1]), g1 = rbf(a[2]), u1 = rbf(a[3]);
             const float s0 = rbf(silu_f(g0)), s1 = rbf(silu_f(g1));
             *(uint32_t*)(cbase + (size_t)((m * ldc + ((uint32_t)ncol[i] >> 1)) * 2u)) = pack2bf(s0 * u0, s1 * u1);
