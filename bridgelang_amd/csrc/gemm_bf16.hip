@@ -54,6 +54,14 @@ __device__ __forceinline__ void tile_coords(const GemmArgs& p, int& tm, int& tn)
   tn = rem / gsz;
 }
 
+// the same mapping for a VIRTUAL block index vb of nwg (persistent kernels: a workgroup walks vb = blockIdx.x + r·gridDim.x;
+// with gridDim.x a multiple of 8 every tile of a workgroup belongs to its own XCD's contiguous run)
+__device__ __forceinline__ void tile_coords_v(const GemmArgs& p, int vb, int nwg, int& tm, int& tn) {
+  const int xcd = vb & 7, q = nwg >> 3, r = nwg & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+  lin_to_tile(p, lin, tm, tn);
+}
+
 #define BL_GLDS(RS, LDSP, VOFF, SOFF) __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, LDS_PTR(LDSP), 16, VOFF, SOFF, 0, 0)
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;   // result of ds_read_b64_tr_b16
 
@@ -1427,15 +1435,25 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
   int tm, tn;
   const int nk_all = TN ? (p.K + BK - 1) / BK : p.K / BK;
   int kt_begin = 0, nk = nk_all;
+  // Persistent form (p.ptiles > 0, round 4): the launch has one workgroup per CU and workgroup b walks tiles b, b + grid,
+  // b + 2·grid … < ptiles of the XCD-contiguous order. The K streams of consecutive tiles are FLATTENED: the loop below
+  // issues its LDS-DMA half-tiles 1.5 K-tiles ahead, and what used to be zero-size loads past the end of K (K-tiles nk,
+  // nk + 1) are now the first two K-tiles of the workgroup's next tile — exactly the seven half-tiles of the prologue, in
+  // its order, into the stages the next tile expects (nk is even) — so the next tile starts with its operands in LDS and
+  // its first fragments in registers, behind this tile's epilogue instead of behind a workgroup launch and a cold prologue.
+  const int ptiles = p.splitk > 1 ? 0 : p.ptiles;
+  int vb = blockIdx.x;                     // virtual block index of the current tile
   if (p.splitk > 1) {
     lin_to_tile(p, p.tail_base + blockIdx.x / p.splitk, tm, tn);
     const int slice = blockIdx.x % p.splitk;
     kt_begin = (int)(((long)slice * nk_all) / p.splitk) & ~1;
     nk = slice + 1 == p.splitk ? nk_all : ((int)(((long)(slice + 1) * nk_all) / p.splitk) & ~1);
+  } else if (ptiles > 0) {
+    tile_coords_v(p, vb, ptiles, tm, tn);
   } else {
     tile_coords(p, tm, tn);
   }
-  const int m0 = tm * BM, n0 = tn * BN;
+  int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -1445,9 +1463,36 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
   // TN (C = Aᵀ·B, the weight gradient dW = dyᵀ·x read UNtransposed): A is [K tokens, M] and W is [K tokens, N], both
   // row-major; a K-tile is 64 token rows of each. The descriptors end with the last token row's last column (the exact
   // extent of a column-slice view), so K-tiles past the end and the ragged last one read zeros.
-  const unsigned a_bytes = (unsigned)min(TN ? ((long)(p.K - 1) * p.lda + p.M) * 2 : (long)p.M * p.lda * 2, 0xffffffffL);
-  const unsigned w_bytes = (unsigned)min(TN ? ((long)(p.K - 1) * p.ldw + p.N) * 2 : (long)p.N * p.K * 2, 0xffffffffL);
+  // The per-lane offsets below are TILE-RELATIVE; the tile's origin goes into the buffer descriptor's base (uniform), and
+  // its size shrinks by the same bytes, so the bounds check (zero-fill past M / N / K) sees what it saw with absolute
+  // offsets. A tile's (base, size) pair is rebuilt per tile from (m0, n0): TILE_A / TILE_W.
+  const long a_total = TN ? ((long)(p.K - 1) * p.lda + p.M) * 2 : (long)p.M * p.lda * 2;
+  const long w_total = TN ? ((long)(p.K - 1) * p.ldw + p.N) * 2 : (long)p.N * p.K * 2;
   const int kstepX = TN ? (int)(64 * p.lda * 2) : 128, kstepY = TN ? (int)(64 * p.ldw * 2) : 2048;
+#define TILE_A_OFF(M0) (TN ? (long)(M0) * 2 : (long)(M0) * p.lda * 2)
+#define TILE_W_OFF(N0) (TN ? (long)(N0) * 2 : (long)((N0) / 16) * (p.K >> 5) * 1024)
+  const char* Acur = (const char*)p.A + TILE_A_OFF(m0);
+  const char* Wcur = (const char*)p.W + TILE_W_OFF(n0);
+  unsigned a_bytes = (unsigned)min(a_total - TILE_A_OFF(m0), 0xffffffffL);
+  unsigned w_bytes = (unsigned)min(w_total - TILE_W_OFF(n0), 0xffffffffL);
+  // the workgroup's NEXT tile (size 0 = none: loads past the end of K write zeros, as they always did)
+  const char* Anext = Acur; const char* Wnext = Wcur;
+  unsigned a_bytes_next = 0u, w_bytes_next = 0u;
+  int m0_next = 0, n0_next = 0;
+#define BL_NEXT_TILE()                                                                      \
+  do {                                                                                      \
+    a_bytes_next = 0u; w_bytes_next = 0u;                                                   \
+    if (ptiles > 0 && vb + (int)gridDim.x < ptiles) {                                       \
+      int tm__, tn__;                                                                       \
+      tile_coords_v(p, vb + (int)gridDim.x, ptiles, tm__, tn__);                            \
+      m0_next = tm__ * BM; n0_next = tn__ * BN;                                             \
+      Anext = (const char*)p.A + TILE_A_OFF(m0_next);                                       \
+      Wnext = (const char*)p.W + TILE_W_OFF(n0_next);                                       \
+      a_bytes_next = (unsigned)min(a_total - TILE_A_OFF(m0_next), 0xffffffffL);             \
+      w_bytes_next = (unsigned)min(w_total - TILE_W_OFF(n0_next), 0xffffffffL);             \
+    }                                                                                       \
+  } while (0)
+  BL_NEXT_TILE();
 
   const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
   unsigned voffX[2][2], voffY[2][2];
@@ -1458,13 +1503,13 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int pi = 2 * wave + j, row0 = (pi >> 3) * 128 + mh * 64 + (pi & 7) * 8;
-        voffX[mh][j] = (unsigned)(((long)(m0 + row0 + prow) * p.lda) * 2 + pchunk * 16);
+        voffX[mh][j] = (unsigned)(((long)(row0 + prow) * p.lda) * 2 + pchunk * 16);
         ldsX[mh][j] = row0 * ROW_BYTES;
       }
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh) {
       const int nt = (wave >> 1) * 4 + 2 * nh + (wave & 1);
-      voffY[nh][0] = (unsigned)((long)(n0 / 16 + nt) * kt32 * 1024 + lane * 16);
+      voffY[nh][0] = (unsigned)((long)nt * kt32 * 1024 + lane * 16);
       voffY[nh][1] = voffY[nh][0] + 1024;
       ldsY[nh] = W_OFF + nt * 2048;
     }
@@ -1479,7 +1524,7 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
       for (int j = 0; j < 2; ++j) {
         const int pi = 2 * wave + j, t = (pi & 7) * 8 + prow, pos = lane & 7;
         const int c = ((((pos >> 1) ^ ((t >> 1) & 3)) << 1) | (pos & 1));
-        voffX[mh][j] = (unsigned)((long)t * p.lda * 2 + (long)(m0 + (pi >> 3) * 128 + mh * 64) * 2 + c * 16);
+        voffX[mh][j] = (unsigned)((long)t * p.lda * 2 + (long)((pi >> 3) * 128 + mh * 64) * 2 + c * 16);
         ldsX[mh][j] = ((pi >> 3) * 128 + mh * 64 + (pi & 7) * 8) * ROW_BYTES;
       }
     // Y half nh = columns nh*128 .. +127 of the tile: [64 tokens][256 B], whole 128-byte lines per piece (4 token rows × 256 B;
@@ -1490,7 +1535,7 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
       for (int j = 0; j < 2; ++j) {
         const int t = (2 * wave + j) * 4 + (lane >> 4), pos = lane & 15;
         const int c = ((((pos >> 1) ^ (t & 7)) << 1) | (pos & 1));
-        voffY[nh][j] = (unsigned)((long)t * p.ldw * 2 + (long)(n0 + nh * 128) * 2 + c * 16);
+        voffY[nh][j] = (unsigned)((long)t * p.ldw * 2 + (long)(nh * 128) * 2 + c * 16);
       }
       ldsY[nh] = W_OFF + nh * 16384 + wave * 2048;
     }
@@ -1500,18 +1545,22 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
 #define ISSUE_X(MH, TILE)                                                                   \
   do {                                                                                      \
     const int t__ = (TILE);                                                                 \
-    const __amdgpu_buffer_rsrc_t rs__ = BL_RS(p.A, t__ < nk ? a_bytes : 0u);                \
+    const bool nx__ = t__ >= nk;                 /* K-tile t - nk of the next tile */        \
+    const int tt__ = nx__ ? t__ - nk : t__;                                                 \
+    const __amdgpu_buffer_rsrc_t rs__ = BL_RS(nx__ ? Anext : Acur, nx__ ? a_bytes_next : a_bytes); \
     char* b__ = smem + (t__ & 1) * STAGE;                                                   \
-    BL_GLDS(rs__, b__ + ldsX[MH][0], voffX[MH][0], t__ * kstepX);                              \
-    BL_GLDS(rs__, b__ + ldsX[MH][1], voffX[MH][1], t__ * kstepX);                              \
+    BL_GLDS(rs__, b__ + ldsX[MH][0], voffX[MH][0], tt__ * kstepX);                             \
+    BL_GLDS(rs__, b__ + ldsX[MH][1], voffX[MH][1], tt__ * kstepX);                             \
   } while (0)
 #define ISSUE_Y(NH, TILE)                                                                   \
   do {                                                                                      \
     const int t__ = (TILE);                                                                 \
-    const __amdgpu_buffer_rsrc_t rs__ = BL_RS(p.W, t__ < nk ? w_bytes : 0u);                \
+    const bool nx__ = t__ >= nk;                                                            \
+    const int tt__ = nx__ ? t__ - nk : t__;                                                 \
+    const __amdgpu_buffer_rsrc_t rs__ = BL_RS(nx__ ? Wnext : Wcur, nx__ ? w_bytes_next : w_bytes); \
     char* b__ = smem + (t__ & 1) * STAGE;                                                   \
-    BL_GLDS(rs__, b__ + ldsY[NH], voffY[NH][0], t__ * kstepY);                                \
-    BL_GLDS(rs__, b__ + ldsY[NH] + 1024, voffY[NH][1], t__ * kstepY);                         \
+    BL_GLDS(rs__, b__ + ldsY[NH], voffY[NH][0], tt__ * kstepY);                               \
+    BL_GLDS(rs__, b__ + ldsY[NH] + 1024, voffY[NH][1], tt__ * kstepY);                        \
   } while (0)
   const int cb0 = (lg ^ (lane & 7)) << 4;
   const int offX = (wm * 128 + l15) * ROW_BYTES;
@@ -1609,9 +1658,12 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
   // 128 accumulator registers of both loops into one assignment)
 #define BL_EPILOGUE()                                                                                     \
   do {                                                                                                    \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+    if (a_bytes_next == 0u && w_bytes_next == 0u)   /* last tile: zero-fill loads must not outlive the LDS */ \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
     if (p.splitk > 1) {                                                                                   \
-      float* dst = p.slab + ((long)blockIdx.x * 32 * 512 + tid) * 4;                                      \
+      long off__ = ((long)blockIdx.x * 32 * 512 + tid) * 4;                                               \
+      asm volatile("" : "+v"(off__));   /* keeps the 32 slab addresses out of the tile loop's preheader (spills) */ \
+      float* dst = p.slab + off__;                                                                        \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) *(f32x4_t*)(dst + (long)(i * 8 + j) * 512 * 4) = acc[i][j]; \
     } else {                                                                                              \
@@ -1620,6 +1672,17 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
         ncol__[i] = TN ? n0 + (i >> 1) * 128 + wn * 32 + (i & 1) * 16 + lg * 4 : n0 + wn * 64 + i * 16 + lg * 4; \
       epilogue_tile<EPI, 4, 8>(p, m0 + wm * 128 + l15, ncol__, m0 + 256, n0 + 256, acc);                  \
     }                                                                                                     \
+  } while (0)
+
+  // after a tile's epilogue: the next tile becomes the current one (its first two K-tiles are in LDS or in flight, its
+  // first fragments in registers), the accumulators restart from zero
+#define BL_ADVANCE()                                                                                      \
+  do {                                                                                                    \
+    vb += (int)gridDim.x;                                                                                 \
+    m0 = m0_next; n0 = n0_next; Acur = Anext; Wcur = Wnext; a_bytes = a_bytes_next; w_bytes = w_bytes_next; \
+    BL_NEXT_TILE();                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};            \
   } while (0)
 
   f32x4_t acc[4][8];
@@ -1645,6 +1708,7 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
     READ_X(X, 0, S0);
     WAIT_LGKM();
     BAR();
+    for (;;) {
     for (int t = t0; t < nk; t += 2) {
       // K-tile t (stage 0): Y0 in Ya, Y1 → Yb
       MMA(X, Ya, 0, 0); WAIT_VM8(); BAR();   ISSUE_READ(ISSUE_Q0(t), READ_Y(Yb, 1, S0)); WAIT_LGKM(); BAR();
@@ -1657,12 +1721,17 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
       MMA(X, Ya, 1, 1); WAIT_VM8(); BAR();   ISSUE_READ(ISSUE_Q2(t + 1), READ_Y(Ya, 0, S0)); WAIT_LGKM(); BAR();
       MMA(X, Yb, 1, 0); WAIT_VM8(); BAR();   ISSUE_READ(ISSUE_Q3(t + 1), READ_X(X, 0, S0));  WAIT_LGKM(); BAR();
     }
+    const bool more = a_bytes_next != 0u;
     BL_EPILOGUE();
+    if (!more) break;
+    BL_ADVANCE();
+    }
     return;
   }
   // ============================== group B: issue + read THIS phase, then MMA ==============================
   WAIT_LGKM();
   BAR();
+  for (;;) {
   for (int t = t0; t < nk; t += 2) {
     ISSUE_READ(ISSUE_Q0(t), READ_X(X, 0, S0));  WAIT_VM10_LGKM(); BAR();   MMA(X, Ya, 0, 0); BAR();
     ISSUE_READ(ISSUE_Q1(t), READ_Y(Yb, 1, S0)); WAIT_VM10_LGKM(); BAR();   MMA(X, Yb, 0, 1); BAR();
@@ -1673,8 +1742,16 @@ __global__ __launch_bounds__(512) void gemm256s_kernel(GemmArgs p) {
     ISSUE_READ(ISSUE_Q2(t + 1), READ_X(X, 1, S1));  WAIT_VM10_LGKM(); BAR();   MMA(X, Ya, 1, 1); BAR();
     ISSUE_READ(ISSUE_Q3(t + 1), READ_Y(Ya, 0, S0)); WAIT_VM10_LGKM(); BAR();   MMA(X, Yb, 1, 0); BAR();
   }
+  const bool more = a_bytes_next != 0u;
   BL_EPILOGUE();
+  if (!more) break;
+  BL_ADVANCE();
+  }
 #undef BL_EPILOGUE
+#undef BL_ADVANCE
+#undef BL_NEXT_TILE
+#undef TILE_A_OFF
+#undef TILE_W_OFF
 #undef ISSUE_X
 #undef ISSUE_Y
 #undef READ_X
@@ -1969,10 +2046,19 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   while (S > 1 && nk / S < 4) --S;
   static const bool no_split = getenv("BL_GEMM_NO_SPLITK") != nullptr;
   static const bool lockstep = getenv("BL_GEMM_LOCKSTEP") != nullptr;   // A/B aid: the non-staggered 256 kernel
+  // more than one round of tiles: the persistent form (one workgroup per CU walks its tiles, the next tile's first K-tiles
+  // land behind this tile's epilogue); needs an even number of K-tiles (stage parity carries over) and 32-bit extents
+  static const bool no_persist = getenv("BL_GEMM_NO_PERSIST") != nullptr;      // A/B aid
+  const bool persist_ok = !no_persist && !lockstep && (nk % 2) == 0 && (long)p.M * p.lda * 2 < (1L << 32) &&
+                          (long)p.N * p.K * 2 < (1L << 32);
 #define BL_LAUNCH256(GRID)                                                                              \
   do {                                                                                                  \
     if (lockstep) hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(GRID), dim3(512), LDS256, s, p);       \
-    else hipLaunchKernelGGL((gemm256s_kernel<EPI>), dim3(GRID), dim3(512), LDS256, s, p);               \
+    else if (persist_ok && p.splitk <= 1 && (GRID) > CUS) {                                             \
+      GemmArgs pp = p;                                                                                  \
+      pp.ptiles = (GRID);                                                                               \
+      hipLaunchKernelGGL((gemm256s_kernel<EPI>), dim3(CUS), dim3(512), LDS256, s, pp);                  \
+    } else hipLaunchKernelGGL((gemm256s_kernel<EPI>), dim3(GRID), dim3(512), LDS256, s, p);             \
   } while (0)
   const bool can_split = tail && S >= 2 && p.K >= 8192 && p.slab &&
                          p.slab_bytes >= (long)tail * S * 256 * 256 * 4 && !no_split && !force;
@@ -2031,14 +2117,26 @@ int launch_gemm_tn(const GemmArgs& a, hipStream_t s) {
   static const bool no_split = getenv("BL_GEMM_NO_SPLITK") != nullptr;
   const bool can_split = tail && S >= 2 && (nk >= 128 || tiles <= CUS) && p.slab &&
                          p.slab_bytes >= (long)tail * S * 256 * 256 * 4 && !no_split;
+  static const bool no_persist = getenv("BL_GEMM_NO_PERSIST") != nullptr;      // A/B aid
+  const bool persist_ok = !no_persist && (nk % 2) == 0 && ((long)(p.K - 1) * p.lda + p.M) * 2 < (1L << 32) &&
+                          ((long)(p.K - 1) * p.ldw + p.N) * 2 < (1L << 32);
+  auto launch_main = [&](int grid) {
+    if (persist_ok && grid > CUS) {
+      GemmArgs pp = p;
+      pp.ptiles = grid;
+      hipLaunchKernelGGL((gemm256s_kernel<BL_EPI_F32, true>), dim3(CUS), dim3(512), LDS256, s, pp);
+    } else {
+      hipLaunchKernelGGL((gemm256s_kernel<BL_EPI_F32, true>), dim3(grid), dim3(512), LDS256, s, p);
+    }
+  };
   if (can_split) {
-    if (tiles > tail) hipLaunchKernelGGL((gemm256s_kernel<BL_EPI_F32, true>), dim3(tiles - tail), dim3(512), LDS256, s, p);
+    if (tiles > tail) launch_main(tiles - tail);
     p.tail_base = tiles - tail;
     p.splitk = S;
     hipLaunchKernelGGL((gemm256s_kernel<BL_EPI_F32, true>), dim3(tail * S), dim3(512), LDS256, s, p);
     hipLaunchKernelGGL((gemm_splitk_reduce_kernel<BL_EPI_F32, true>), dim3(tail * 32), dim3(512), 0, s, p);
   } else {
-    hipLaunchKernelGGL((gemm256s_kernel<BL_EPI_F32, true>), dim3(tiles), dim3(512), LDS256, s, p);
+    launch_main(tiles);
   }
   BL_CHECK_LAUNCH();
   return BL_OK;

@@ -19,6 +19,7 @@ struct GemmArgs {
   const float* qa; const float* qw;   // fp8 GEMM: per-row activation / per-column weight dequantisation scales
   int fold_ks;   // gemm_mid_kernel<SK>: MFMA k-steps per K-slice (skinny summation order); 0 = off
   uint16_t* C2; long ldc2;   // second output of the *_KEEP training epilogues
+  int ptiles;   // gemm256s persistent form: > 0 = the launch walks this many tiles with one workgroup per CU (0 = one tile per workgroup)
 };
 
 __device__ __forceinline__ int out_row_of(const GemmArgs& p, int m) {
@@ -222,6 +223,7 @@ inline int fill_gemm_args(const bl_gemm_desc* d, GemmArgs& a) {
   a.qa = a.qw = nullptr;
   a.fold_ks = 0;
   a.C2 = (uint16_t*)d->C2; a.ldc2 = d->ldc2;
+  a.ptiles = 0;
   return BL_OK;
 }
 

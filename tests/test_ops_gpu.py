@@ -191,6 +191,43 @@ def test_gemm288_sequence_tiles(dev, M, N, K, epi):
         assert torch.equal(one, out[s0:s0 + 288]), f"rows {s0}..: result depends on the tiling"
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(2333, 15360, 256, "bias"), (2560, 15344, 384, "none"), (2333, 15360, 256, "swiglu"),
+                                       (2500, 15360, 128, "res")])
+def test_gemm256_persistent_multi_round(dev, M, N, K, epi):
+    """More than one round of 256 x 256 tiles with a partial last round of > 64 tiles (600 tiles: 88 workgroups walk three
+    tiles, 168 walk two) goes to the PERSISTENT form of gemm256s_kernel — one workgroup per CU, the next tile's first
+    K-tiles staged behind this tile's epilogue. Ragged M and N (edge tiles take the per-store epilogue, interior tiles
+    the straight-line one), even K-tile counts 2 … 6, four epilogue families: against the oracle on sampled rows, and —
+    since a row's K order is the same in every tile kernel — bit-identical to 288-row slices run on their own (mid
+    kernels)."""
+    from bridgelang_amd import ops
+    a, w, b, r = rand_bf16((M, K), 1), rand_bf16((N, K), 2, 0.05), rand_bf16((N,), 3, 0.1), rand_bf16((M, N), 4)
+    A, Bv, Rr = dv(a, dev), dv(b, dev), dv(r, dev)
+    sel = torch.cat([torch.arange(0, 150), torch.arange(1200, 1350), torch.arange(M - 150, M)])
+    if epi == "swiglu":
+        I = N // 2
+        W = pk(torch.stack([w[:I], w[I:]], 1).reshape(N, K), dev)
+        out = torch.empty(M, I, dtype=torch.bfloat16, device=dev)
+        kw, e = {}, ops.EPI_SWIGLU
+        g, u = R.linear(P, a[sel], w[:I]), R.linear(P, a[sel], w[I:])
+        ref = P.rb(P.rb(torch.nn.functional.silu(g)) * u)
+    else:
+        W = pk(w, dev)
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        kw, e = {"res": dict(res=Rr), "bias": dict(bias=Bv), "none": {}}[epi], {"res": ops.EPI_RES, "bias": ops.EPI_BIAS, "none": ops.EPI_NONE}[epi]
+        ref = {"res": lambda: P.rb(r[sel] + R.linear(P, a[sel], w)), "bias": lambda: R.linear(P, a[sel], w, b),
+               "none": lambda: R.linear(P, a[sel], w)}[epi]()
+    out.fill_(float("nan"))
+    ops.gemm(A, W, out, e, **kw)
+    assert not torch.isnan(out.float()).any(), "a tile of the persistent walk was never written"
+    close_bf16(out[sel], ref, f"gemm256 persistent {epi}")
+    for s0 in (0, 288 * 3, M - 288):
+        one = torch.empty(288, out.shape[1], dtype=torch.bfloat16, device=dev)
+        kw1 = {k: (v[s0:s0 + 288] if k == "res" else v) for k, v in kw.items()}
+        ops.gemm(A[s0:s0 + 288], W, one, e, **kw1)
+        assert torch.equal(one, out[s0:s0 + 288]), f"rows {s0}..: result depends on the tiling"
+
+
 @pytest.mark.parametrize("T,N,K", [(261, 1024, 1024), (256, 1152, 4352), (256, 1024, 640)])
 def test_gemm_ring160_vit_shapes_and_batch_invariance(dev, T, N, K):
     """The narrow ViT layers at 16 images (attn.proj / mlp.fc2 / patch embed: M = 16·T rows, N ≤ 1152) run as ONE round of
@@ -617,7 +654,10 @@ def test_gemm_mid_rows(dev, M, N, K, epi):
 
 @pytest.mark.parametrize("Tn,N,K,pad", [(4736, 4096, 4096, 0), (300, 1152, 2176, 0), (261 * 4, 1024, 4096, 0),
                                         (9472, 5632, 4096, 0), (1000, 512, 768, 64), (64, 256, 256, 0), (37, 264, 520, 8),
-                                        (4176, 3072, 1024, 0), (4176, 1152, 4304, 0)])
+                                        (4176, 3072, 1024, 0), (4176, 1152, 4304, 0),
+                                        # 288 tiles: persistent walk without a workspace (even K-tile count, ragged last
+                                        # K-tile) / one tile per workgroup (odd K-tile count)
+                                        (1000, 2304, 8192, 0), (1044, 4608, 4096, 0)])
 def test_gemm_tn_matches_fp32_matmul(dev, Tn, N, K, pad):
     """bl_gemm_tn_bf16: out[N, K] = dyᵀ·x read untransposed (weight gradient of nn.Linear; torch autograd's
     `grad_output.t().mm(input)`). Ragged token counts, partial 256-tiles, column-slice views (ld > cols) and the K-split
