@@ -117,13 +117,14 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n,
 // bias / residual load latency per call behind its guards: + 4–5 µs per one-round GEMM for a bias add, + 13 µs with GELU
 // (tools/bench_gemm_shapes.py). The arithmetic per element is the same statements in the same order as epilogue_store4's.
 // Ragged edge tiles, remapped rows and the training epilogues go through epilogue_store4 as before.
-template <int EPI, int NI, int NJ>
+template <int EPI, int NI, int NJ, bool WIDE = true>
 __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, int mrow, const int (&ncol)[NI], int m_end, int n_end,
                                               f32x4_t (&acc)[NI][NJ]) {
   constexpr bool kHasBias = EPI == BL_EPI_BIAS || EPI == BL_EPI_BIAS_GELU || EPI == BL_EPI_BIAS_RES;
   constexpr bool kHasRes = EPI == BL_EPI_BIAS_RES || EPI == BL_EPI_RES;
   constexpr bool kF32 = EPI == BL_EPI_F32 || EPI == BL_EPI_F32_BF16R;      // fp32 output (weight gradients, logits)
   constexpr bool kFast = EPI == BL_EPI_NONE || kHasBias || kHasRes || EPI == BL_EPI_SWIGLU || kF32;
+  constexpr bool kWide = WIDE && (NI % 2) == 0 && !kF32 && EPI != BL_EPI_SWIGLU;   // needs ncol[i + 1] == ncol[i] + 16, i even
   if constexpr (kFast) {
     const bool plain = p.out_group == 0 && p.res_row_mod == 0 && m_end <= p.M && n_end <= p.N &&
                        (long)p.M * p.ldc * (kF32 ? 4 : 2) < (1L << 32) && (!kHasRes || (long)p.M * p.ldres * 2 < (1L << 32));
@@ -140,6 +141,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, int mrow, const
       }
       char* const cbase = (char*)p.C;
       const char* const rbase = (const char*)p.res;
+      const int lg_ = (int)((threadIdx.x & 63u) >> 4);
+      const int wide_dc = -4 * lg_ + (lg_ & 1) * 16 + (lg_ >> 1) * 8;    // this lane's first column after the swap, relative
+      u32x2_t held = {0u, 0u};
       const uint32_t ldc = (uint32_t)p.ldc, ldres = (uint32_t)p.ldres;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -179,7 +183,23 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, int mrow, const
               v[0] += bflo(rq[i][0]); v[1] += bfhi(rq[i][0]); v[2] += bflo(rq[i][1]); v[3] += bfhi(rq[i][1]);
             }
             u32x2_t o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-            *(u32x2_t*)(cbase + (size_t)((m * ldc + (uint32_t)ncol[i]) * 2u)) = o;
+            if constexpr (kWide) {
+              // 16-byte stores: column groups i (even) and i + 1 lie 16 columns apart and a lane row lg owns columns
+              // 4 lg … 4 lg + 3 of each. v_permlane16_swap trades the odd lane rows of group i against the even lane rows
+              // of group i + 1, after which lane rows 0 / 2 hold columns 0-7 / 8-15 of group i and lane rows 1 / 3 those of
+              // group i + 1: one dwordx4 per lane and pair instead of two dwordx2 — half the store instructions, 64
+              // contiguous bytes per output row and instruction instead of 32 (the one-round GEMMs' store tail).
+              if ((i & 1) == 0) {
+                held = o;
+              } else {
+                const auto r0 = __builtin_amdgcn_permlane16_swap(held[0], o[0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(held[1], o[1], false, false);
+                const u32x4_t w = {r0[0], r1[0], r0[1], r1[1]};
+                *(u32x4_t*)(cbase + (size_t)((m * ldc + (uint32_t)(ncol[i - 1] + wide_dc)) * 2u)) = w;
+              }
+            } else {
+              *(u32x2_t*)(cbase + (size_t)((m * ldc + (uint32_t)ncol[i]) * 2u)) = o;
+            }
           }
         }
       }
