@@ -124,6 +124,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, int mrow, const
   constexpr bool kHasRes = EPI == BL_EPI_BIAS_RES || EPI == BL_EPI_RES;
   constexpr bool kF32 = EPI == BL_EPI_F32 || EPI == BL_EPI_F32_BF16R;      // fp32 output (weight gradients, logits)
   constexpr bool kFast = EPI == BL_EPI_NONE || kHasBias || kHasRes || EPI == BL_EPI_SWIGLU || kF32;
+  constexpr bool kWideSwiglu = WIDE && (NI % 4) == 0 && EPI == BL_EPI_SWIGLU;   // needs ncol[i + 1] == ncol[i] + 16 within each group of 4
   constexpr bool kWide = WIDE && (NI % 2) == 0 && !kF32 && EPI != BL_EPI_SWIGLU;   // needs ncol[i + 1] == ncol[i] + 16, i even
   if constexpr (kFast) {
     const bool plain = p.out_group == 0 && p.res_row_mod == 0 && m_end <= p.M && n_end <= p.N &&
@@ -144,6 +145,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, int mrow, const
       const int lg_ = (int)((threadIdx.x & 63u) >> 4);
       const int wide_dc = -4 * lg_ + (lg_ & 1) * 16 + (lg_ >> 1) * 8;    // this lane's first column after the swap, relative
       u32x2_t held = {0u, 0u};
+      const int wide_dc_sw = -2 * lg_ + 8 * lg_;    // SWIGLU: lane row r stores activation columns 8 r … 8 r + 7 of the four groups
+      uint32_t sw[4] = {0u, 0u, 0u, 0u};
       const uint32_t ldc = (uint32_t)p.ldc, ldres = (uint32_t)p.ldres;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -163,7 +166,24 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, int mrow, const
           } else if constexpr (EPI == BL_EPI_SWIGLU) {
             const float g0 = rbf(a[0]), u0 = rbf(a[1]), g1 = rbf(a[2]), u1 = rbf(a[3]);
             const float s0 = rbf(silu_f(g0)), s1 = rbf(silu_f(g1));
-            *(uint32_t*)(cbase + (size_t)((m * ldc + ((uint32_t)ncol[i] >> 1)) * 2u)) = pack2bf(s0 * u0, s1 * u1);
+            const uint32_t o = pack2bf(s0 * u0, s1 * u1);
+            if constexpr (kWideSwiglu) {
+              // a lane row lg owns ONE dword (activation columns 2 lg, 2 lg + 1) of each of the four column groups, which lie
+              // 8 activation columns apart: a 4 x 4 transpose over (group, lane row) — permlane16_swap on the pairs (0, 1),
+              // (2, 3), then permlane32_swap on (0, 2), (1, 3) — leaves lane row r with the four dwords of group r: one
+              // dwordx4 (8 columns) per lane instead of four dword stores
+              sw[i & 3] = o;
+              if ((i & 3) == 3) {
+                const auto p01 = __builtin_amdgcn_permlane16_swap(sw[0], sw[1], false, false);
+                const auto p23 = __builtin_amdgcn_permlane16_swap(sw[2], sw[3], false, false);
+                const auto q02 = __builtin_amdgcn_permlane32_swap(p01[0], p23[0], false, false);
+                const auto q13 = __builtin_amdgcn_permlane32_swap(p01[1], p23[1], false, false);
+                const u32x4_t w = {q02[0], q13[0], q02[1], q13[1]};
+                *(u32x4_t*)(cbase + (size_t)((m * ldc + (uint32_t)((ncol[i - 3] >> 1) + wide_dc_sw)) * 2u)) = w;
+              }
+            } else {
+              *(uint32_t*)(cbase + (size_t)((m * ldc + ((uint32_t)ncol[i] >> 1)) * 2u)) = o;
+            }
           } else {
             float v[4] = {a[0], a[1], a[2], a[3]};
             if constexpr (kHasBias) {
