@@ -120,118 +120,154 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n,
 template <int EPI, int NI, int NJ, bool WIDE = true>
 __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, int mrow, const int (&ncol)[NI], int m_end, int n_end,
                                               f32x4_t (&acc)[NI][NJ]) {
-  constexpr bool kHasBias = EPI == BL_EPI_BIAS || EPI == BL_EPI_BIAS_GELU || EPI == BL_EPI_BIAS_RES;
+  constexpr bool kHasBias = EPI == BL_EPI_BIAS || EPI == BL_EPI_BIAS_GELU || EPI == BL_EPI_BIAS_RES || EPI == BL_EPI_BIAS_GELU_KEEP;
   constexpr bool kHasRes = EPI == BL_EPI_BIAS_RES || EPI == BL_EPI_RES;
+  constexpr bool kReadsRes = kHasRes || EPI == BL_EPI_SWIGLU_BWD || EPI == BL_EPI_GELU_BWD;
+  constexpr bool kHasC2 = EPI == BL_EPI_SWIGLU_KEEP || EPI == BL_EPI_BIAS_GELU_KEEP;
   constexpr bool kF32 = EPI == BL_EPI_F32 || EPI == BL_EPI_F32_BF16R;      // fp32 output (weight gradients, logits)
-  constexpr bool kFast = EPI == BL_EPI_NONE || kHasBias || kHasRes || EPI == BL_EPI_SWIGLU || kF32;
-  constexpr bool kWideSwiglu = WIDE && (NI % 4) == 0 && EPI == BL_EPI_SWIGLU;   // needs ncol[i + 1] == ncol[i] + 16 within each group of 4
-  constexpr bool kWide = WIDE && (NI % 2) == 0 && !kF32 && EPI != BL_EPI_SWIGLU;   // needs ncol[i + 1] == ncol[i] + 16, i even
-  if constexpr (kFast) {
-    const bool plain = p.out_group == 0 && p.res_row_mod == 0 && m_end <= p.M && n_end <= p.N &&
-                       (long)p.M * p.ldc * (kF32 ? 4 : 2) < (1L << 32) && (!kHasRes || (long)p.M * p.ldres * 2 < (1L << 32));
-    if (plain) {
-      u32x2_t bq[NI], sq[NI];
+  // 16-byte stores need ncol[i + 1] == ncol[i] + 16 within each pair (8-byte outputs) / group of four (4-byte outputs)
+  constexpr bool kWide2 = WIDE && (NI % 2) == 0, kWide4 = WIDE && (NI % 4) == 0;
+  const bool plain = p.out_group == 0 && p.res_row_mod == 0 && m_end <= p.M && n_end <= p.N &&
+                     (long)p.M * p.ldc * (kF32 ? 4 : 2) < (1L << 32) && (!kReadsRes || (long)p.M * p.ldres * 2 < (1L << 32)) &&
+                     (!kHasC2 || (long)p.M * p.ldc2 * 2 < (1L << 32));
+  if (plain) {
+    u32x2_t bq[NI], sq[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      bq[i] = (u32x2_t){0u, 0u};
+      sq[i] = (u32x2_t){0x3f803f80u, 0x3f803f80u};                 // 1.0: rbf(v · 1) == v for a bf16-valued v
+      if constexpr (kHasBias) bq[i] = *(const u32x2_t*)(p.bias + ncol[i]);
+      if constexpr (EPI == BL_EPI_BIAS_RES) {
+        if (p.scale != nullptr) sq[i] = *(const u32x2_t*)(p.scale + ncol[i]);
+      }
+    }
+    char* const cbase = (char*)p.C;
+    char* const c2base = (char*)p.C2;
+    const char* const rbase = (const char*)p.res;
+    const int lg_ = (int)((threadIdx.x & 63u) >> 4);
+    const uint32_t ldc = (uint32_t)p.ldc, ldres = (uint32_t)p.ldres, ldc2 = (uint32_t)p.ldc2;
+    // 16-byte stores of 8-byte outputs: column groups i (even) and i + 1 lie 16 columns apart and a lane row lg owns columns
+    // 4 lg … 4 lg + 3 of each. v_permlane16_swap trades the odd lane rows of group i against the even lane rows of group
+    // i + 1, after which lane rows 0 / 2 hold columns 0-7 / 8-15 of group i and lane rows 1 / 3 those of group i + 1: one
+    // dwordx4 per lane and pair instead of two dwordx2 — half the store instructions, 64 contiguous bytes per output row
+    // and instruction instead of 32 (the one-round GEMMs' store tail).
+    const int wide_dc = -4 * lg_ + (lg_ & 1) * 16 + (lg_ >> 1) * 8;      // this lane's first column after the swap, relative
+    auto store8 = [&](char* base, uint32_t ld, uint32_t m, int i, u32x2_t o, u32x2_t& held) {
+      if constexpr (kWide2) {
+        if ((i & 1) == 0) {
+          held = o;
+        } else {
+          const auto r0 = __builtin_amdgcn_permlane16_swap(held[0], o[0], false, false);
+          const auto r1 = __builtin_amdgcn_permlane16_swap(held[1], o[1], false, false);
+          const u32x4_t w = {r0[0], r1[0], r0[1], r1[1]};
+          *(u32x4_t*)(base + (size_t)((m * ld + (uint32_t)(ncol[i - 1] + wide_dc)) * 2u)) = w;
+        }
+      } else {
+        *(u32x2_t*)(base + (size_t)((m * ld + (uint32_t)ncol[i]) * 2u)) = o;
+      }
+    };
+    // 16-byte stores of 4-byte outputs (SwiGLU activations, column n >> 1): a lane row lg owns ONE dword (activation columns
+    // 2 lg, 2 lg + 1) of each of four column groups, which lie 8 activation columns apart: a 4 x 4 transpose over (group, lane
+    // row) — permlane16_swap on the pairs (0, 1), (2, 3), then permlane32_swap on (0, 2), (1, 3) — leaves lane row r with the
+    // four dwords of group r: one dwordx4 (8 columns) per lane instead of four dword stores
+    const int wide_dc_sw = 6 * lg_;                                      // lane row r stores activation columns 8 r … 8 r + 7
+    auto store4 = [&](char* base, uint32_t ld, uint32_t m, int i, uint32_t o, uint32_t (&sw)[4]) {
+      if constexpr (kWide4) {
+        sw[i & 3] = o;
+        if ((i & 3) == 3) {
+          const auto p01 = __builtin_amdgcn_permlane16_swap(sw[0], sw[1], false, false);
+          const auto p23 = __builtin_amdgcn_permlane16_swap(sw[2], sw[3], false, false);
+          const auto q02 = __builtin_amdgcn_permlane32_swap(p01[0], p23[0], false, false);
+          const auto q13 = __builtin_amdgcn_permlane32_swap(p01[1], p23[1], false, false);
+          const u32x4_t w = {q02[0], q13[0], q02[1], q13[1]};
+          *(u32x4_t*)(base + (size_t)((m * ld + (uint32_t)((ncol[i - 3] >> 1) + wide_dc_sw)) * 2u)) = w;
+        }
+      } else {
+        *(uint32_t*)(base + (size_t)((m * ld + ((uint32_t)ncol[i] >> 1)) * 2u)) = o;
+      }
+    };
+    u32x2_t held = {0u, 0u}, held2 = {0u, 0u};
+    uint32_t sw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const uint32_t m = (uint32_t)(mrow + j * 16);
+      u32x2_t rq[NI];
+      u32x4_t rq4[NI];
+      if constexpr (kHasRes || EPI == BL_EPI_GELU_BWD) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) rq[i] = *(const u32x2_t*)(rbase + (size_t)((m * ldres + (uint32_t)ncol[i]) * 2u));
+      }
+      if constexpr (EPI == BL_EPI_SWIGLU_BWD) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) rq4[i] = *(const u32x4_t*)(rbase + (size_t)((m * ldres + 2u * (uint32_t)ncol[i]) * 2u));
+      }
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        bq[i] = (u32x2_t){0u, 0u};
-        sq[i] = (u32x2_t){0x3f803f80u, 0x3f803f80u};                 // 1.0: rbf(v · 1) == v for a bf16-valued v
-        if constexpr (kHasBias) bq[i] = *(const u32x2_t*)(p.bias + ncol[i]);
-        if constexpr (EPI == BL_EPI_BIAS_RES) {
-          if (p.scale != nullptr) sq[i] = *(const u32x2_t*)(p.scale + ncol[i]);
-        }
-      }
-      char* const cbase = (char*)p.C;
-      const char* const rbase = (const char*)p.res;
-      const int lg_ = (int)((threadIdx.x & 63u) >> 4);
-      const int wide_dc = -4 * lg_ + (lg_ & 1) * 16 + (lg_ >> 1) * 8;    // this lane's first column after the swap, relative
-      u32x2_t held = {0u, 0u};
-      const int wide_dc_sw = -2 * lg_ + 8 * lg_;    // SWIGLU: lane row r stores activation columns 8 r … 8 r + 7 of the four groups
-      uint32_t sw[4] = {0u, 0u, 0u, 0u};
-      const uint32_t ldc = (uint32_t)p.ldc, ldres = (uint32_t)p.ldres;
+        const f32x4_t a = acc[i][j];
+        if constexpr (kF32) {
+          f32x4_t o = a;
+          if constexpr (EPI == BL_EPI_F32_BF16R) o = (f32x4_t){rbf(a[0]), rbf(a[1]), rbf(a[2]), rbf(a[3])};
+          *(f32x4_t*)(cbase + (size_t)((m * ldc + (uint32_t)ncol[i]) * 4u)) = o;
+        } else if constexpr (EPI == BL_EPI_SWIGLU) {
+          const float g0 = rbf(a[0]), u0 = rbf(a[1]), g1 = rbf(a[2]), u1 = rbf(a[3]);
+          const float s0 = rbf(silu_f(g0)), s1 = rbf(silu_f(g1));
+          store4(cbase, ldc, m, i, pack2bf(s0 * u0, s1 * u1), sw);
+        } else if constexpr (EPI == BL_EPI_SWIGLU_KEEP) {
+          const float g0 = rbf(a[0]), u0 = rbf(a[1]), g1 = rbf(a[2]), u1 = rbf(a[3]);
+          u32x2_t o; o[0] = pack2bf(g0, u0); o[1] = pack2bf(g1, u1);
+          store8(cbase, ldc, m, i, o, held);
+          store4(c2base, ldc2, m, i, pack2bf(rbf(silu_f(g0)) * u0, rbf(silu_f(g1)) * u1), sw);
+        } else if constexpr (EPI == BL_EPI_SWIGLU_BWD) {
+          float v[8], o[8];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const uint32_t m = (uint32_t)(mrow + j * 16);
-        u32x2_t rq[NI];
-        if constexpr (kHasRes) {
+          for (int e = 0; e < 4; ++e) { v[2 * e] = bflo(rq4[i][e]); v[2 * e + 1] = bfhi(rq4[i][e]); }
 #pragma unroll
-          for (int i = 0; i < NI; ++i) rq[i] = *(const u32x2_t*)(rbase + (size_t)((m * ldres + (uint32_t)ncol[i]) * 2u));
-        }
+          for (int e = 0; e < 4; ++e) swiglu_bwd_pair(v[2 * e], v[2 * e + 1], rbf(a[e]), o[2 * e], o[2 * e + 1]);
+          u32x4_t w;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const f32x4_t a = acc[i][j];
-          if constexpr (kF32) {
-            f32x4_t o = a;
-            if constexpr (EPI == BL_EPI_F32_BF16R) o = (f32x4_t){rbf(a[0]), rbf(a[1]), rbf(a[2]), rbf(a[3])};
-            *(f32x4_t*)(cbase + (size_t)((m * ldc + (uint32_t)ncol[i]) * 4u)) = o;
-          } else if constexpr (EPI == BL_EPI_SWIGLU) {
-            const float g0 = rbf(a[0]), u0 = rbf(a[1]), g1 = rbf(a[2]), u1 = rbf(a[3]);
-            const float s0 = rbf(silu_f(g0)), s1 = rbf(silu_f(g1));
-            const uint32_t o = pack2bf(s0 * u0, s1 * u1);
-            if constexpr (kWideSwiglu) {
-              // a lane row lg owns ONE dword (activation columns 2 lg, 2 lg + 1) of each of the four column groups, which lie
-              // 8 activation columns apart: a 4 x 4 transpose over (group, lane row) — permlane16_swap on the pairs (0, 1),
-              // (2, 3), then permlane32_swap on (0, 2), (1, 3) — leaves lane row r with the four dwords of group r: one
-              // dwordx4 (8 columns) per lane instead of four dword stores
-              sw[i & 3] = o;
-              if ((i & 3) == 3) {
-                const auto p01 = __builtin_amdgcn_permlane16_swap(sw[0], sw[1], false, false);
-                const auto p23 = __builtin_amdgcn_permlane16_swap(sw[2], sw[3], false, false);
-                const auto q02 = __builtin_amdgcn_permlane32_swap(p01[0], p23[0], false, false);
-                const auto q13 = __builtin_amdgcn_permlane32_swap(p01[1], p23[1], false, false);
-                const u32x4_t w = {q02[0], q13[0], q02[1], q13[1]};
-                *(u32x4_t*)(cbase + (size_t)((m * ldc + (uint32_t)((ncol[i - 3] >> 1) + wide_dc_sw)) * 2u)) = w;
-              }
-            } else {
-              *(uint32_t*)(cbase + (size_t)((m * ldc + ((uint32_t)ncol[i] >> 1)) * 2u)) = o;
-            }
-          } else {
-            float v[4] = {a[0], a[1], a[2], a[3]};
-            if constexpr (kHasBias) {
-              v[0] += bflo(bq[i][0]); v[1] += bfhi(bq[i][0]); v[2] += bflo(bq[i][1]); v[3] += bfhi(bq[i][1]);
-            }
-            if constexpr (EPI == BL_EPI_BIAS_GELU) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = gelu_erf(rbf(v[e]));
-            }
-            if constexpr (kHasRes) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
-              if constexpr (EPI == BL_EPI_BIAS_RES) {
-                v[0] = rbf(v[0] * bflo(sq[i][0])); v[1] = rbf(v[1] * bfhi(sq[i][0]));
-                v[2] = rbf(v[2] * bflo(sq[i][1])); v[3] = rbf(v[3] * bfhi(sq[i][1]));
-              }
-              v[0] += bflo(rq[i][0]); v[1] += bfhi(rq[i][0]); v[2] += bflo(rq[i][1]); v[3] += bfhi(rq[i][1]);
-            }
-            u32x2_t o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-            if constexpr (kWide) {
-              // 16-byte stores: column groups i (even) and i + 1 lie 16 columns apart and a lane row lg owns columns
-              // 4 lg … 4 lg + 3 of each. v_permlane16_swap trades the odd lane rows of group i against the even lane rows
-              // of group i + 1, after which lane rows 0 / 2 hold columns 0-7 / 8-15 of group i and lane rows 1 / 3 those of
-              // group i + 1: one dwordx4 per lane and pair instead of two dwordx2 — half the store instructions, 64
-              // contiguous bytes per output row and instruction instead of 32 (the one-round GEMMs' store tail).
-              if ((i & 1) == 0) {
-                held = o;
-              } else {
-                const auto r0 = __builtin_amdgcn_permlane16_swap(held[0], o[0], false, false);
-                const auto r1 = __builtin_amdgcn_permlane16_swap(held[1], o[1], false, false);
-                const u32x4_t w = {r0[0], r1[0], r0[1], r1[1]};
-                *(u32x4_t*)(cbase + (size_t)((m * ldc + (uint32_t)(ncol[i - 1] + wide_dc)) * 2u)) = w;
-              }
-            } else {
-              *(u32x2_t*)(cbase + (size_t)((m * ldc + (uint32_t)ncol[i]) * 2u)) = o;
-            }
+          for (int e = 0; e < 4; ++e) w[e] = pack2bf(o[2 * e], o[2 * e + 1]);
+          *(u32x4_t*)(cbase + (size_t)((m * ldc + 2u * (uint32_t)ncol[i]) * 2u)) = w;
+        } else if constexpr (EPI == BL_EPI_GELU_BWD) {
+          u32x2_t o;
+          o[0] = pack2bf(rbf(a[0]) * gelu_erf_grad(bflo(rq[i][0])), rbf(a[1]) * gelu_erf_grad(bfhi(rq[i][0])));
+          o[1] = pack2bf(rbf(a[2]) * gelu_erf_grad(bflo(rq[i][1])), rbf(a[3]) * gelu_erf_grad(bfhi(rq[i][1])));
+          store8(cbase, ldc, m, i, o, held);
+        } else {
+          float v[4] = {a[0], a[1], a[2], a[3]};
+          if constexpr (kHasBias) {
+            v[0] += bflo(bq[i][0]); v[1] += bfhi(bq[i][0]); v[2] += bflo(bq[i][1]); v[3] += bfhi(bq[i][1]);
           }
+          if constexpr (EPI == BL_EPI_BIAS_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(rbf(v[e]));
+          }
+          if constexpr (EPI == BL_EPI_BIAS_GELU_KEEP) {     // C keeps t = bf16(acc + bias), C2 gets gelu(t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
+            u32x2_t a2; a2[0] = pack2bf(gelu_erf(v[0]), gelu_erf(v[1])); a2[1] = pack2bf(gelu_erf(v[2]), gelu_erf(v[3]));
+            store8(c2base, ldc2, m, i, a2, held2);
+          }
+          if constexpr (kHasRes) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
+            if constexpr (EPI == BL_EPI_BIAS_RES) {
+              v[0] = rbf(v[0] * bflo(sq[i][0])); v[1] = rbf(v[1] * bfhi(sq[i][0]));
+              v[2] = rbf(v[2] * bflo(sq[i][1])); v[3] = rbf(v[3] * bfhi(sq[i][1]));
+            }
+            v[0] += bflo(rq[i][0]); v[1] += bfhi(rq[i][0]); v[2] += bflo(rq[i][1]); v[3] += bfhi(rq[i][1]);
+          }
+          u32x2_t o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+          store8(cbase, ldc, m, i, o, held);
         }
       }
-      return;
     }
+    return;
   }
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) epilogue_store4<EPI>(p, mrow + j * 16, ncol[i], acc[i][j]);
 }
-
 
 // host side: validate a descriptor and copy it into the device argument block
 inline int fill_gemm_args(const bl_gemm_desc* d, GemmArgs& a) {

@@ -37,11 +37,12 @@ IGNORE_INDEX = -100
 WGRAD_NT = os.environ.get("BL_WGRAD_NT", "") not in ("", "0")     # A/B aid: weight gradients through transposed copies
 WGRAD_FP8_5PASS = os.environ.get("BL_WGRAD_FP8_5PASS", "") not in ("", "0")   # A/B aid: round 3's five passes per e4m3 wgrad operand pair
 # SwiGLU / GELU forward ("f") and backward ("b") as GEMM epilogues (BL_EPI_*_KEEP / BL_EPI_*_BWD) instead of separate
-# elementwise passes. OFF by default — measured on one MI355X at 7B, B = 32 (round 4, same box, alternating runs): separate
-# passes 442.2 ms / step, backward fused 442.7, forward fused 446.2, both 444.5. The tile GEMM holds one workgroup per CU, so
-# its epilogue is fully exposed (the matrix pipes idle while 512 lanes store); the extra stores / exp / erf of a fused
-# activation cost more there than the HBM-bound pass they remove (which runs at 5 TB/s). Bit-identical either way.
-_FA = os.environ.get("BL_TRAIN_FUSED_ACT", "")
+# elementwise passes. ON by default since the tile GEMMs' whole-tile epilogue (round 4, gemm_common.h::epilogue_tile): same box,
+# alternating runs at 7B, B = 32: separate passes 409.8 ms / step, forward fused 408.7, backward fused 409.0, both 406.6. With the
+# per-store epilogue of rounds 1-3 the fused forms LOST 2-4 ms (442.2 vs 444.5-446.2): one workgroup per CU, so the extra
+# stores / exp / erf sat exposed in an epilogue that already cost more than the HBM-bound pass they remove.
+# BL_TRAIN_FUSED_ACT=0 (or any string without "f" / "b") selects the separate passes. Bit-identical either way (tested).
+_FA = os.environ.get("BL_TRAIN_FUSED_ACT", "fb")
 UNFUSED_FWD, UNFUSED_BWD = "f" not in _FA, "b" not in _FA
 
 # stage → (vision trainable, projector trainable, llm: "all" | "last" | "none")   — prismatic.py:129-241
@@ -1063,7 +1064,7 @@ class TrainStep:
     def _lin_act(self, x, packed, pre, act, kind: str, **kw) -> List[Op]:
         """Linear + activation of the training forward with the PRE-activation kept (autograd's saved tensor): one GEMM
         whose epilogue writes both (`kind` "swiglu": gate/up interleaved → silu(g)·u; "gelu": bias + exact-erf GELU). The
-        e4m3 path and the default (BL_TRAIN_FUSED_ACT unset, see above) keep the plain epilogue + an elementwise pass; both forms
+        e4m3 path and BL_TRAIN_FUSED_ACT=0 (see above) keep the plain epilogue + an elementwise pass; both forms
         give the same bits."""
         fused = not UNFUSED_FWD and self._w8.get(packed.data_ptr()) is None
         if kind == "swiglu":
@@ -1077,7 +1078,7 @@ class TrainStep:
     def _lin_bwd_act(self, dy, x, packed, pre, dpre, dact, kind: str) -> List[Op]:
         """Backward of `act(pre)` → Linear(packed) given dy of the linear: the input-gradient GEMM's epilogue applies the
         activation's backward with the saved pre-activation, so d act never travels through HBM (dact is only used by the
-        unfused forms: e4m3 dgrad and the default)."""
+        unfused forms: e4m3 dgrad and BL_TRAIN_FUSED_ACT=0)."""
         fused = not UNFUSED_BWD and self._w8.get(packed.data_ptr()) is None
         if not fused:
             bwd = T.swiglu_backward(pre, dact, dpre, run=False) if kind == "swiglu" else T.gelu_backward(pre, dact, dpre, run=False)

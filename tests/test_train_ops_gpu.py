@@ -339,7 +339,8 @@ def test_pack_into_windows(dev):
     assert torch.equal(WTe, ops.pack_weight(dv(torch.cat([w.t(), a.t()], 1).contiguous(), dev)))
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (9472 // 8, 1024, 512), (70, 64, 192)])
+# the last shape runs on the 256 x 256 tile kernel (576 tiles, persistent walk, ragged last row tile): whole-tile epilogue path
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (9472 // 8, 1024, 512), (70, 64, 192), (4500, 8192, 256)])
 def test_training_epilogues_equal_the_two_kernel_forms(dev, M, N, K):
     """The training-step GEMM epilogues (BL_EPI_SWIGLU_KEEP / BIAS_GELU_KEEP / SWIGLU_BWD / GELU_BWD) must reproduce, bit for
     bit, the plain epilogue followed by the elementwise kernel they replace (bl_swiglu_bf16, bl_gelu_bf16,
