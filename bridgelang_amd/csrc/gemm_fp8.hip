@@ -159,9 +159,12 @@ __global__ __launch_bounds__(512) void gemm256s_fp8_kernel(GemmArgs p) {
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
           const int m__ = m0 + wm * 128 + j * 16 + l15;                                                   \
           const float sa__ = m__ < p.M ? p.qa[m__] : 0.f;                                                 \
-          epilogue_store4<EPI>(p, m__, n__, acc[i][j] * sw__ * sa__);                                     \
+          acc[i][j] = acc[i][j] * sw__ * sa__;          /* dequantise in place, then the whole-tile epilogue */ \
         }                                                                                                 \
       }                                                                                                   \
+      const int ncol__[4] = {n0 + wn * 64 + lg * 4, n0 + wn * 64 + 16 + lg * 4, n0 + wn * 64 + 32 + lg * 4,       \
+                             n0 + wn * 64 + 48 + lg * 4};                                                 \
+      epilogue_tile<EPI, 4, 8>(p, m0 + wm * 128 + l15, ncol__, m0 + 256, n0 + 256, acc);                  \
     }                                                                                                     \
   } while (0)
 

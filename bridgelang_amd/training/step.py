@@ -1080,6 +1080,8 @@ class TrainStep:
         activation's backward with the saved pre-activation, so d act never travels through HBM (dact is only used by the
         unfused forms: e4m3 dgrad and BL_TRAIN_FUSED_ACT=0)."""
         fused = not UNFUSED_BWD and self._w8.get(packed.data_ptr()) is None
+        if self.lora is not None and self.lora.dropout > 0.0 and self.lora.get(packed) is not None:
+            fused = False       # dropout's backward adds the masked adapter share to d act BEFORE the activation's backward
         if not fused:
             bwd = T.swiglu_backward(pre, dact, dpre, run=False) if kind == "swiglu" else T.gelu_backward(pre, dact, dpre, run=False)
             return self._lin_bwd(dy, x, packed, dact) + [bwd]
