@@ -390,7 +390,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
   // Two fragment register sets: the reads of K-tile kt+1 are issued among the MFMAs of K-tile kt (after the barrier that
   // says kt+1 has landed), so no wave ever waits on LDS at the head of a K-step — with one set all eight waves read their
   // 14 fragments right behind the barrier (≈ 450 LDS cycles per CU with no MFMA in flight: 0.58 µs per K-step measured).
-  // The loop is unrolled by two K-steps for the set swap (the launcher requires K % 128 == 0).
+  // The loop is unrolled by two K-steps for the set swap; an odd last K-step follows the loop.
   bf16x8_t wf[2][2][NT], af[2][2][MT];
 #define BL_READ(SET, BASE, RI)                                                                                   \
   do {                                                                                                           \
@@ -422,10 +422,11 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int ri = 0; ri < NRD; ++ri) BL_READ(0, smem, ri);
-  for (int kt = 0; kt < nk; kt += 2) {
+  for (int kt = 0; kt + 1 < nk; kt += 2) {
     BL_KSTEP(0, 1, kt);
     BL_KSTEP(1, 0, kt + 1);
   }
+  if (nk & 1) BL_KSTEP(0, 1, nk - 1);    // odd K-tile count (LoRA's K + rank columns): one more step from set 0, outside the loop
 #undef BL_KSTEP
 #undef BL_READ
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus stages must not outlive the workgroup's LDS allocation
@@ -1984,7 +1985,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
       p.tiles_n = (p.N + 127) / 128;
       p.tail_base = -1;
       static const bool ring_w4 = getenv("BL_GEMM_RING160_W4") != nullptr;      // A/B aid: the one-wave-per-SIMD form
-      if (ring_w4 || (p.K % 128)) hipLaunchKernelGGL((gemm_tail_kernel<EPI, 160, 128, 4>), dim3(t160), dim3(256), 4 * 288 * ROW_BYTES, s, p);
+      if (ring_w4) hipLaunchKernelGGL((gemm_tail_kernel<EPI, 160, 128, 4>), dim3(t160), dim3(256), 4 * 288 * ROW_BYTES, s, p);
       else hipLaunchKernelGGL((gemm_ring8_kernel<EPI, 160, 128, 4>), dim3(t160), dim3(512), 4 * 288 * ROW_BYTES + 1024, s, p);
       BL_CHECK_LAUNCH();
       return BL_OK;

@@ -228,7 +228,7 @@ def test_gemm256_persistent_multi_round(dev, M, N, K, epi):
         assert torch.equal(one, out[s0:s0 + 288]), f"rows {s0}..: result depends on the tiling"
 
 
-@pytest.mark.parametrize("T,N,K", [(261, 1024, 1024), (256, 1152, 4352), (256, 1024, 640)])
+@pytest.mark.parametrize("T,N,K", [(261, 1024, 1024), (256, 1152, 4352), (256, 1024, 640), (261, 1024, 1088)])   # last: odd K-tile count (LoRA: K + rank columns)
 def test_gemm_ring160_vit_shapes_and_batch_invariance(dev, T, N, K):
     """The narrow ViT layers at 16 images (attn.proj / mlp.fc2 / patch embed: M = 16·T rows, N ≤ 1152) run as ONE round of
     160 × 128 tiles on the ring-buffered kernel (gemm_tail_kernel stand-alone mode): vs the oracle with the fused
