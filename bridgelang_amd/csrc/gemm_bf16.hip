@@ -376,10 +376,19 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BK;
+  // grid.y > 1 slices K (few-tile, long-K problems — LoRA's rank projections t = x·Aᵀ / dt = dy·(sB): 37 row tiles, N = 64 … 192,
+  // K up to 22016 — which gemm128's one-stage prefetch ran at one global-load latency per K-step, ≈ 19.5 µs per call): every
+  // slice writes its fp32 partial [M, N] to the slab, gemm128_splitk_reduce_kernel sums them in slice order + epilogue
+  const int nk_all = p.K / BK;
+  int ktb = 0, nk = nk_all;
+  const bool sliced = p.splitk > 1;
+  if (sliced) {
+    ktb = (int)(((long)blockIdx.y * nk_all) / p.splitk);
+    nk = (int)(((long)(blockIdx.y + 1) * nk_all) / p.splitk) - ktb;
+  }
 #pragma unroll
   for (int s2 = 0; s2 < NST - 1; ++s2) {
-    const int kt0 = min(s2, nk - 1);
+    const int kt0 = ktb + min(s2, nk - 1);
 #pragma unroll
     for (int pc = 0; pc < LPS; ++pc) BL_PIECE(s2, kt0, pc);
   }
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
     __builtin_amdgcn_s_barrier();   /* … for every wave; every wave has its fragments of K-tile KT-1 and older */ \
     const char* nb__ = smem + (((KT) + 1) % NST) * BUF_BYTES;                                                    \
     const int nslot__ = ((KT) + NST - 1) % NST;                      /* the slot of K-tile KT-1 */               \
-    const int nkt__ = min((KT) + NST - 1, nk - 1);                                                               \
+    const int nkt__ = ktb + min((KT) + NST - 1, nk - 1);                                                         \
     _Pragma("unroll") for (int g = 0; g < LPS; ++g) {                                                            \
       BL_PIECE(nslot__, nkt__, g);                                                                               \
       _Pragma("unroll") for (int ri = g * RPG; ri < ((g + 1) * RPG < NRD ? (g + 1) * RPG : NRD); ++ri)           \
@@ -431,6 +440,17 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
 #undef BL_READ
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus stages must not outlive the workgroup's LDS allocation
 #undef BL_PIECE
+  if (sliced) {
+    float* slab = p.slab + (long)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int m = m0 + wm * TM + j * 16 + l15, n = n0 + wn * TN + i * 16 + lg * 4;
+        if (m < p.M && n < p.N) *(f32x4_t*)(slab + (long)m * p.N + n) = acc[i][j];
+      }
+    return;
+  }
   int ncol[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) ncol[i] = n0 + wn * TN + i * 16 + lg * 4;
@@ -1890,6 +1910,8 @@ int set_lds_attr() {
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 288 * ROW_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring8_kernel<EPI, 160, 128, 4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 288 * ROW_BYTES + 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring8_kernel<EPI, 128, 128, 4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * ROW_BYTES + 1024) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mid2_kernel<EPI, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             3 * (160 * ROW_BYTES + 4096)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mid2_kernel<EPI, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1998,11 +2020,18 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     // few tiles, long K (tall-skinny): slice K over grid.y when the caller gave a workspace (opt-in, as for the 256
     // kernel: sliced sums are not batch-slot invariant)
     int S128 = 1;
+    static const bool ring_split = getenv("BL_GEMM_SPLITK_128") == nullptr;   // A/B aid: set → gemm128's split-K form
     if (p.slab && tiles <= CUS / 2 && !force && !getenv("BL_GEMM_NO_SPLITK")) {
-      S128 = min(8, (2 * CUS) / tiles);
+      // the ring kernel holds one workgroup per CU (129 KiB of LDS), gemm128 two
+      S128 = min(8, ((ring_split ? 1 : 2) * CUS) / tiles);
       while (S128 > 1 && (nk128 / S128 < 8 || p.slab_bytes < (long)S128 * p.M * p.N * 4)) --S128;
     }
-    if (S128 > 1) {
+    if (S128 > 1 && ring_split) {
+      p.splitk = S128;
+      hipLaunchKernelGGL((gemm_ring8_kernel<EPI, 128, 128, 4>), dim3(tiles, S128), dim3(512), 4 * 256 * ROW_BYTES + 1024, s, p);
+      const long work = (long)p.M * (p.N / 4);
+      hipLaunchKernelGGL((gemm128_splitk_reduce_kernel<EPI>), dim3((int)min((work + 255) / 256, 2048L)), dim3(256), 0, s, p);
+    } else if (S128 > 1) {
       p.splitk = S128;
       hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(tiles, S128), dim3(256), LDS128, s, p);
       const long work = (long)p.M * (p.N / 4);
