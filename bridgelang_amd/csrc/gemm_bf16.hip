@@ -317,7 +317,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_tail_kernel(GemmArgs p) {
 template <int EPI, int BM, int BN, int NST>
 __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int WNW = 4, NWAVE = 8, TM = BM / 2, TN = BN / WNW, MT = TM / 16, NT = TN / 16;
+  constexpr int NWAVE = 8, TM = BM / 2, TN = BN / 4, MT = TM / 16, NT = TN / 16;      // waves: 2 along m x 4 along n
   constexpr int APIECES = BM / 8, WPIECES = BN / 8;
   constexpr int APW = (APIECES + NWAVE - 1) / NWAVE, WPW = WPIECES / NWAVE, LPS = APW + WPW;
   static_assert(TM % 16 == 0 && TN % 16 == 0 && WPIECES % NWAVE == 0, "tile shape");

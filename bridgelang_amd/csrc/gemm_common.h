@@ -116,7 +116,10 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int n,
 // around each 8-byte store (bounds guards, exec save / restore, the row-remap branch, two 64-bit multiplies) and exposed one
 // bias / residual load latency per call behind its guards: + 4–5 µs per one-round GEMM for a bias add, + 13 µs with GELU
 // (tools/bench_gemm_shapes.py). The arithmetic per element is the same statements in the same order as epilogue_store4's.
-// Ragged edge tiles, remapped rows and the training epilogues go through epilogue_store4 as before.
+// Every epilogue family has the straight-line form (the training *_KEEP / *_BWD ones since the same round: fused SwiGLU / GELU
+// forward and backward became a net win with it). Ragged edge tiles and remapped / wrapped rows go through epilogue_store4 as
+// before. Outputs leave as 16-byte stores (store8 / store4 below), which requires ncol[i + 1] == ncol[i] + 16 inside each pair
+// (8-byte outputs) or group of four (SwiGLU's 4-byte outputs) of column groups — true of every caller.
 template <int EPI, int NI, int NJ, bool WIDE = true>
 __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, int mrow, const int (&ncol)[NI], int m_end, int n_end,
                                               f32x4_t (&acc)[NI][NJ]) {
