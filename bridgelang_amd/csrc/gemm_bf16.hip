@@ -326,7 +326,16 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
 
   const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
   const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-  const int m0 = (lin / p.tiles_n) * BM, n0 = (lin % p.tiles_n) * BN;
+  int m0, n0;
+  if (p.tail_base >= 0) {   // tail mode (as gemm_tail_kernel): SUBS sub-tiles per leftover 256 × 256 tile of the big kernel's grid
+    constexpr int SUB_N = 256 / BN, SUBS = (256 / BM) * SUB_N;
+    int tm, tn;
+    lin_to_tile(p, p.tail_base + lin / SUBS, tm, tn);
+    const int sub = lin % SUBS;
+    m0 = tm * 256 + (sub / SUB_N) * BM, n0 = tn * 256 + (sub % SUB_N) * BN;
+  } else {
+    m0 = (lin / p.tiles_n) * BM, n0 = (lin % p.tiles_n) * BN;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(512) void gemm_ring8_kernel(GemmArgs p) {
   // slice writes its fp32 partial [M, N] to the slab, gemm128_splitk_reduce_kernel sums them in slice order + epilogue
   const int nk_all = p.K / BK;
   int ktb = 0, nk = nk_all;
-  const bool sliced = p.splitk > 1;
+  const bool sliced = p.splitk > 1 && p.tail_base < 0;
   if (sliced) {
     ktb = (int)(((long)blockIdx.y * nk_all) / p.splitk);
     nk = (int)(((long)(blockIdx.y + 1) * nk_all) / p.splitk) - ktb;
@@ -1912,6 +1921,10 @@ int set_lds_attr() {
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 288 * ROW_BYTES + 1024) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring8_kernel<EPI, 128, 128, 4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * ROW_BYTES + 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring8_kernel<EPI, 128, 64, 4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 192 * ROW_BYTES + 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring8_kernel<EPI, 64, 64, 4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * ROW_BYTES + 1024) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mid2_kernel<EPI, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             3 * (160 * ROW_BYTES + 4096)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mid2_kernel<EPI, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2108,13 +2121,22 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
       // leftover 256x256 tiles, cut so that the sub-tiles cover (up to) every CU once
       p.tail_base = main_tiles;
       static const bool old_tail = getenv("BL_GEMM_OLD_TAIL") != nullptr;   // A/B aid
+      static const bool tail_w4 = getenv("BL_GEMM_TAIL_W4") != nullptr;     // A/B aid: the one-wave-per-SIMD tail kernels
       if (old_tail) hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(tail * 4), dim3(256), LDS128, s, p);
-      else if (tail <= 16)
+      else if (tail_w4 && tail <= 16)
         hipLaunchKernelGGL((gemm_tail_kernel<EPI, 64, 64, 4>), dim3(tail * 16), dim3(256), 4 * 128 * ROW_BYTES, s, p);
-      else if (tail <= 32)
+      else if (tail_w4 && tail <= 32)
         hipLaunchKernelGGL((gemm_tail_kernel<EPI, 128, 64, 4>), dim3(tail * 8), dim3(256), 4 * 192 * ROW_BYTES, s, p);
-      else
+      else if (tail_w4)
         hipLaunchKernelGGL((gemm_tail_kernel<EPI, 128, 128, 4>), dim3(tail * 4), dim3(256), 4 * 256 * ROW_BYTES, s, p);
+      // two waves per SIMD (gemm_ring8_kernel in tail mode): the sub-tiles' K-steps are LDS-DMA issue + fragment reads + MFMAs
+      // of ONE wave per SIMD back to back otherwise
+      else if (tail <= 16)
+        hipLaunchKernelGGL((gemm_ring8_kernel<EPI, 64, 64, 4>), dim3(tail * 16), dim3(512), 4 * 128 * ROW_BYTES + 1024, s, p);
+      else if (tail <= 32)
+        hipLaunchKernelGGL((gemm_ring8_kernel<EPI, 128, 64, 4>), dim3(tail * 8), dim3(512), 4 * 192 * ROW_BYTES + 1024, s, p);
+      else
+        hipLaunchKernelGGL((gemm_ring8_kernel<EPI, 128, 128, 4>), dim3(tail * 4), dim3(512), 4 * 256 * ROW_BYTES + 1024, s, p);
     }
   }
 #undef BL_LAUNCH256
